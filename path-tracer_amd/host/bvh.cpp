@@ -1,0 +1,514 @@
+#include "bvh.hpp"
+
+#include <algorithm>
+#include <atomic>
+#include <cstring>
+#include <iostream>
+#include <thread>
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// reference_order: the reference's bucketed top-down build (src/bvh.cpp:150-262), restated with an
+// explicit work stack (the reference recurses once per node, as deep as the tree) and
+// structure-of-arrays scratch.  What must be reproduced for bit-identical output:
+//   * count 1 / 2 are leaves; count <= 4 sorts the range by centroid on the PARENT box's longest
+//     axis and halves it; otherwise 12 centroid buckets on that axis, cost
+//     0.125 + (nL*SA_L + nR*SA_R) / SA_parent in fp32, first strict minimum, and the split POSITION
+//     is the number of primitives in buckets <= best -- applied to the range in its current order
+//     (the range is not partitioned by bucket).
+//   * child boxes are recomputed from the actual members of each half.
+// ------------------------------------------------------------------------------------------------
+struct ref_tree {
+    struct node {
+        aabb box;
+        int32_t left = -1;  // right child = left + 1
+        int32_t prim = -1;
+    };
+    std::vector<node> nodes;
+};
+
+constexpr uint32_t kRefBuckets = 12;
+
+aabb range_bounds(const std::vector<aabb>& prim_box, const std::vector<int32_t>& order, uint32_t begin, uint32_t end) {
+    aabb b;
+    for (uint32_t i = begin; i < end; i++) b.union_with(prim_box[order[i]]);
+    return b;
+}
+
+// Number of primitives that go left for a range of more than four primitives.
+uint32_t ref_bucket_split(const std::vector<triangle>& tris, const std::vector<aabb>& prim_box,
+                          const std::vector<int32_t>& order, uint32_t begin, uint32_t end, const aabb& parent_box,
+                          int32_t axis) {
+    uint32_t counts[kRefBuckets] = {};
+    aabb boxes[kRefBuckets];
+
+    aabb centroid_bounds;
+    for (uint32_t i = begin; i < end; i++) centroid_bounds.union_with(tris[order[i]].center);
+
+    const float extent = centroid_bounds.maximum[axis] - centroid_bounds.minimum[axis];
+    if (!(extent > 0.f)) {
+        throw bvh_build_error(
+            "reference_order build does not terminate: every centroid of a >4-triangle range is equal on the split axis");
+    }
+    for (uint32_t i = begin; i < end; i++) {
+        const float offset = (tris[order[i]].center[axis] - centroid_bounds.minimum[axis]) / extent;
+        uint32_t b = (uint32_t)(offset * (float)kRefBuckets);
+        if (b == kRefBuckets) b -= 1;
+        counts[b]++;
+        boxes[b].union_with(prim_box[order[i]]);
+    }
+
+    float cost[kRefBuckets - 1];
+    const float parent_area = parent_box.surface_area();
+    for (uint32_t s = 0; s + 1 < kRefBuckets; s++) {
+        aabb lbox, rbox;
+        float ln = 0.f, rn = 0.f;
+        for (uint32_t i = 0; i <= s; i++) { lbox.union_with(boxes[i]); ln += (float)counts[i]; }
+        for (uint32_t i = s + 1; i < kRefBuckets; i++) { rbox.union_with(boxes[i]); rn += (float)counts[i]; }
+        const float l = ln * lbox.surface_area();
+        const float r = rn * rbox.surface_area();
+        cost[s] = 0.125f + (l + r) / parent_area;
+    }
+    uint32_t best = 0;
+    for (uint32_t s = 1; s + 1 < kRefBuckets; s++) {
+        if (cost[s] < cost[best]) best = s;
+    }
+    uint32_t left_count = 0;
+    for (uint32_t i = 0; i <= best; i++) left_count += counts[i];
+    return left_count;
+}
+
+ref_tree build_reference_order(const std::vector<triangle>& tris) {
+    const uint32_t n = (uint32_t)tris.size();
+    ref_tree t;
+    t.nodes.resize(2 * (size_t)n - 1);
+
+    std::vector<aabb> prim_box(n);
+    std::vector<int32_t> order(n);
+    for (uint32_t i = 0; i < n; i++) { prim_box[i] = aabb(tris[i]); order[i] = (int32_t)i; }
+
+    auto make_leaf = [&](uint32_t id, int32_t prim) {
+        t.nodes[id].box = prim_box[prim];
+        t.nodes[id].prim = prim;
+        t.nodes[id].left = -1;
+    };
+
+    struct work { uint32_t id, begin, end; };
+    std::vector<work> stack;
+    uint32_t next_id = 0;
+    t.nodes[0].box = range_bounds(prim_box, order, 0, n);
+    stack.push_back({ 0, 0, n });
+
+    while (!stack.empty()) {
+        const work w = stack.back();
+        stack.pop_back();
+        const uint32_t count = w.end - w.begin;
+        if (count == 1) { make_leaf(w.id, order[w.begin]); continue; }
+
+        const uint32_t left = ++next_id;
+        const uint32_t right = ++next_id;
+        t.nodes[w.id].left = (int32_t)left;
+        if (count == 2) {
+            make_leaf(left, order[w.begin]);
+            make_leaf(right, order[w.begin + 1]);
+            continue;
+        }
+
+        const aabb parent_box = t.nodes[w.id].box;
+        const int32_t axis = parent_box.maximum_axis();
+        uint32_t left_count;
+        if (count <= 4) {
+            // libstdc++'s std::sort on <= 16 elements is a (stable) insertion sort.
+            std::stable_sort(order.begin() + w.begin, order.begin() + w.end,
+                             [&](int32_t a, int32_t b) { return tris[a].center[axis] < tris[b].center[axis]; });
+            left_count = count / 2;
+        } else {
+            left_count = ref_bucket_split(tris, prim_box, order, w.begin, w.end, parent_box, axis);
+            if (left_count == 0 || left_count >= count) {
+                throw bvh_build_error("reference_order build does not terminate: empty split");
+            }
+        }
+        const uint32_t mid = w.begin + left_count;
+        t.nodes[left].box = range_bounds(prim_box, order, w.begin, mid);
+        t.nodes[right].box = range_bounds(prim_box, order, mid, w.end);
+        stack.push_back({ right, mid, w.end });  // left subtree is numbered first
+        stack.push_back({ left, w.begin, mid });
+    }
+    return t;
+}
+
+// Depth-first renumbering + skip links (src/bvh.cpp:264-279), then the 32-byte records.
+void thread_tree(const ref_tree& t, std::vector<packed_bvh_node>& out) {
+    const size_t n = t.nodes.size();
+    out.assign(n, packed_bvh_node{});
+    std::vector<int32_t> df(n, -1), skip(n, -1);
+
+    struct visit { int32_t id, next; };
+    std::vector<visit> stack;
+    stack.push_back({ 0, -1 });
+    int32_t counter = 0;
+    while (!stack.empty()) {
+        const visit v = stack.back();
+        stack.pop_back();
+        df[v.id] = counter++;
+        skip[v.id] = v.next;
+        const int32_t left = t.nodes[v.id].left;
+        if (left > 0) {
+            stack.push_back({ left + 1, v.next });
+            stack.push_back({ left, left + 1 });
+        }
+    }
+    for (size_t id = 0; id < n; id++) {
+        const auto& src = t.nodes[id];
+        packed_bvh_node& dst = out[df[id]];
+        dst.primitive_id = src.prim;
+        for (int a = 0; a < 3; a++) { dst.min[a] = src.box.minimum.v[a]; dst.max[a] = src.box.maximum.v[a]; }
+        dst.next_id = skip[id] == -1 ? -1 : df[skip[id]];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// sah_partitioned: binned SAH over all three axes, primitives partitioned in place.
+// ------------------------------------------------------------------------------------------------
+struct sah_node {
+    aabb box;
+    int32_t left = -1, right = -1;  // indices into the same vector; -1/-1 = leaf
+    uint32_t first = 0, count = 0;  // leaf range in `order`
+};
+
+constexpr int kSahBins = 16;
+constexpr uint32_t kForceMedianDepth = 44;  // past this depth split at the object median: bounds the depth
+
+struct sah_builder {
+    const std::vector<triangle>& tris;
+    const std::vector<aabb>& prim_box;
+    std::vector<int32_t>& order;
+    uint32_t leaf_max;
+    float traversal_cost, triangle_cost;
+
+    // Splits [begin, end) in place; returns the split point, or begin when the range should be a leaf.
+    uint32_t split(uint32_t begin, uint32_t end, const aabb& box, uint32_t depth) const {
+        const uint32_t count = end - begin;
+        if (count <= 1) return begin;
+
+        aabb cb;
+        for (uint32_t i = begin; i < end; i++) cb.union_with(tris[order[i]].center);
+
+        int best_axis = -1, best_bin = -1;
+        float best_cost = std::numeric_limits<float>::infinity();
+        if (depth < kForceMedianDepth) {
+            for (int axis = 0; axis < 3; axis++) {
+                const float lo = cb.minimum.v[axis];
+                const float extent = cb.maximum.v[axis] - lo;
+                if (!(extent > 0.f)) continue;
+                const float scale = (float)kSahBins / extent;
+                uint32_t bin_count[kSahBins] = {};
+                aabb bin_box[kSahBins];
+                for (uint32_t i = begin; i < end; i++) {
+                    int b = (int)((tris[order[i]].center.v[axis] - lo) * scale);
+                    b = b < 0 ? 0 : (b >= kSahBins ? kSahBins - 1 : b);
+                    bin_count[b]++;
+                    bin_box[b].union_with(prim_box[order[i]]);
+                }
+                float right_area[kSahBins];
+                uint32_t right_count[kSahBins];
+                aabb acc;
+                uint32_t n = 0;
+                for (int b = kSahBins - 1; b > 0; b--) {
+                    acc.union_with(bin_box[b]);
+                    n += bin_count[b];
+                    right_area[b] = n ? acc.surface_area() : 0.f;
+                    right_count[b] = n;
+                }
+                acc = aabb();
+                n = 0;
+                for (int b = 0; b + 1 < kSahBins; b++) {
+                    acc.union_with(bin_box[b]);
+                    n += bin_count[b];
+                    if (n == 0 || right_count[b + 1] == 0) continue;
+                    const float c = (float)n * acc.surface_area() + (float)right_count[b + 1] * right_area[b + 1];
+                    if (c < best_cost) { best_cost = c; best_axis = axis; best_bin = b; }
+                }
+            }
+        }
+
+        const float area = box.surface_area();
+        if (best_axis >= 0 && count <= leaf_max) {
+            const float split_cost = traversal_cost + triangle_cost * best_cost / (area > 0.f ? area : 1.f);
+            if (split_cost >= triangle_cost * (float)count) return begin;  // leaf is cheaper
+        }
+
+        if (best_axis >= 0) {
+            const float lo = cb.minimum.v[best_axis];
+            const float scale = (float)kSahBins / (cb.maximum.v[best_axis] - lo);
+            auto mid = std::partition(order.begin() + begin, order.begin() + end, [&](int32_t p) {
+                int b = (int)((tris[p].center.v[best_axis] - lo) * scale);
+                b = b < 0 ? 0 : (b >= kSahBins ? kSahBins - 1 : b);
+                return b <= best_bin;
+            });
+            const uint32_t m = (uint32_t)(mid - order.begin());
+            if (m > begin && m < end) return m;
+        }
+        // No usable SAH split (coincident centroids, or depth limit): object median on the longest axis.
+        if (count <= leaf_max) return begin;
+        const int axis = box.maximum_axis();
+        const uint32_t m = begin + count / 2;
+        std::nth_element(order.begin() + begin, order.begin() + m, order.begin() + end, [&](int32_t a, int32_t b) {
+            const float ca = tris[a].center.v[axis], cb2 = tris[b].center.v[axis];
+            return ca < cb2 || (ca == cb2 && a < b);
+        });
+        return m;
+    }
+
+    // Depth-first build of one subtree into `nodes`; nodes[root] must already hold its box.
+    void build(std::vector<sah_node>& nodes, uint32_t root, uint32_t begin, uint32_t end, uint32_t depth) const {
+        struct work { uint32_t id, begin, end, depth; };
+        std::vector<work> stack{ { root, begin, end, depth } };
+        while (!stack.empty()) {
+            const work w = stack.back();
+            stack.pop_back();
+            const aabb box = nodes[w.id].box;
+            const uint32_t m = split(w.begin, w.end, box, w.depth);
+            if (m == w.begin) {
+                nodes[w.id].first = w.begin;
+                nodes[w.id].count = w.end - w.begin;
+                continue;
+            }
+            const uint32_t l = (uint32_t)nodes.size();
+            nodes.emplace_back();
+            nodes.emplace_back();
+            nodes[l].box = range_bounds(prim_box, order, w.begin, m);
+            nodes[l + 1].box = range_bounds(prim_box, order, m, w.end);
+            nodes[w.id].left = (int32_t)l;
+            nodes[w.id].right = (int32_t)l + 1;
+            stack.push_back({ l + 1, m, w.end, w.depth + 1 });
+            stack.push_back({ l, w.begin, m, w.depth + 1 });
+        }
+    }
+};
+
+// Builds the SAH tree with `threads` workers: the top of the tree is split breadth-first on the
+// calling thread until there are enough independent ranges, which are then built concurrently
+// (each into its own node vector) and stitched back.
+std::vector<sah_node> build_sah(const std::vector<triangle>& tris, std::vector<int32_t>& order, uint32_t leaf_max,
+                                unsigned threads) {
+    const uint32_t n = (uint32_t)tris.size();
+    std::vector<aabb> prim_box(n);
+    order.resize(n);
+    for (uint32_t i = 0; i < n; i++) { prim_box[i] = aabb(tris[i]); order[i] = (int32_t)i; }
+
+    sah_builder b{ tris, prim_box, order, leaf_max, 1.0f, 1.0f };
+    std::vector<sah_node> nodes(1);
+    nodes[0].box = range_bounds(prim_box, order, 0, n);
+
+    if (threads == 0) threads = std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+    if (threads <= 1 || n < 65536) {
+        b.build(nodes, 0, 0, n, 0);
+        return nodes;
+    }
+
+    struct pending { uint32_t id, begin, end, depth; };
+    std::vector<pending> frontier{ { 0, 0, n, 0 } };
+    const uint32_t grain = std::max<uint32_t>(4096, n / (threads * 8));
+    for (;;) {
+        // split the largest frontier range until all are below the grain (or cannot be split)
+        size_t big = frontier.size();
+        uint32_t big_count = grain;
+        for (size_t i = 0; i < frontier.size(); i++) {
+            const uint32_t c = frontier[i].end - frontier[i].begin;
+            if (c > big_count) { big = i; big_count = c; }
+        }
+        if (big == frontier.size() || frontier.size() >= 4096) break;
+        const pending p = frontier[big];
+        const uint32_t m = b.split(p.begin, p.end, nodes[p.id].box, p.depth);
+        if (m == p.begin) {  // became a leaf
+            nodes[p.id].first = p.begin;
+            nodes[p.id].count = p.end - p.begin;
+            frontier.erase(frontier.begin() + big);
+            continue;
+        }
+        const uint32_t l = (uint32_t)nodes.size();
+        nodes.emplace_back();
+        nodes.emplace_back();
+        nodes[l].box = range_bounds(prim_box, order, p.begin, m);
+        nodes[l + 1].box = range_bounds(prim_box, order, m, p.end);
+        nodes[p.id].left = (int32_t)l;
+        nodes[p.id].right = (int32_t)l + 1;
+        frontier[big] = { l, p.begin, m, p.depth + 1 };
+        frontier.push_back({ l + 1, m, p.end, p.depth + 1 });
+    }
+
+    std::vector<std::vector<sah_node>> sub(frontier.size());
+    std::atomic<size_t> next{ 0 };
+    auto worker = [&]() {
+        for (;;) {
+            const size_t i = next.fetch_add(1);
+            if (i >= frontier.size()) return;
+            const pending& p = frontier[i];
+            sub[i].assign(1, sah_node{});
+            sub[i][0].box = nodes[p.id].box;
+            b.build(sub[i], 0, p.begin, p.end, p.depth);
+        }
+    };
+    std::vector<std::thread> pool;
+    for (unsigned t = 0; t < threads; t++) pool.emplace_back(worker);
+    for (auto& t : pool) t.join();
+
+    for (size_t i = 0; i < frontier.size(); i++) {
+        const uint32_t base = (uint32_t)nodes.size();  // sub[i][k], k >= 1, lands at base + k - 1
+        auto remap = [&](int32_t k) { return k < 0 ? k : (int32_t)(base + (uint32_t)k - 1); };
+        sah_node root = sub[i][0];
+        root.left = remap(root.left);
+        root.right = remap(root.right);
+        nodes[frontier[i].id] = root;
+        for (size_t k = 1; k < sub[i].size(); k++) {
+            sah_node nd = sub[i][k];
+            nd.left = remap(nd.left);
+            nd.right = remap(nd.right);
+            nodes.push_back(nd);
+        }
+    }
+    return nodes;
+}
+
+void fill_flat_triangle(flat_bvh_triangle& out, const triangle& t, int32_t prim, int32_t rank) {
+    const float* a = t.p1.v;
+    const float* b = t.p2.v;
+    const float* c = t.p3.v;
+    float e1[3], e2[3];
+    for (int i = 0; i < 3; i++) { e1[i] = b[i] - a[i]; e2[i] = c[i] - a[i]; out.p0[i] = a[i]; out.e1[i] = e1[i]; out.e2[i] = e2[i]; }
+    out.n[0] = e1[1] * e2[2] - e2[1] * e1[2];
+    out.n[1] = e1[2] * e2[0] - e2[2] * e1[0];
+    out.n[2] = e1[0] * e2[1] - e2[0] * e1[1];
+    out.rank = rank;
+    out.primitive_id = prim;
+    out.pad0 = out.pad1 = 0;
+}
+
+}  // namespace
+
+bvh::bvh(std::vector<triangle>& tris, std::vector<packed_bvh_node>& packed_nodes)
+    : bvh(tris, packed_nodes, build_mode::reference_order) {}
+
+bvh::bvh(std::vector<triangle>& tris, std::vector<packed_bvh_node>& packed_nodes, build_mode mode)
+    : triangles(tris), packed(&packed_nodes) {
+    if (tris.empty()) throw bvh_build_error("bvh: no triangles");
+    if (mode == build_mode::reference_order) {
+        thread_tree(build_reference_order(tris), packed_nodes);
+        return;
+    }
+    // sah_partitioned in the threaded layout: one triangle per leaf, same 32-byte records.
+    std::vector<int32_t> order;
+    const std::vector<sah_node> nodes = build_sah(tris, order, 1, 0);
+    ref_tree t;
+    t.nodes.resize(nodes.size());
+    // children must be adjacent (right = left + 1) for the threaded numbering: build_sah allocates them so.
+    for (size_t i = 0; i < nodes.size(); i++) {
+        t.nodes[i].box = nodes[i].box;
+        t.nodes[i].left = nodes[i].left;
+        t.nodes[i].prim = nodes[i].left < 0 ? order[nodes[i].first] : -1;
+    }
+    thread_tree(t, packed_nodes);
+}
+
+void bvh::exporter() {
+    std::cout << "digraph bvh {\n";
+    if (packed) {
+        // parent -> child edges recovered from the threaded array: an inner node's children are
+        // id + 1 and the skip target of id + 1.
+        const auto& nodes = *packed;
+        for (size_t id = 0; id < nodes.size(); id++) {
+            if (nodes[id].primitive_id != -1) continue;
+            std::cout << "\t" << id << " -> " << id + 1 << ";\n";
+            std::cout << "\t" << id << " -> " << nodes[id + 1].next_id << ";\n";
+        }
+    }
+    std::cout << "}\n";
+}
+
+std::vector<int32_t> bvh::visit_ranks(const std::vector<packed_bvh_node>& packed_nodes, size_t primitive_count) {
+    std::vector<int32_t> ranks(primitive_count, -1);
+    int32_t r = 0;
+    for (const auto& nd : packed_nodes) {
+        if (nd.primitive_id >= 0 && (size_t)nd.primitive_id < primitive_count) ranks[nd.primitive_id] = r++;
+    }
+    return ranks;
+}
+
+std::vector<uint8_t> bvh::flatten(const std::vector<triangle>& tris, const std::vector<int32_t>& ranks, unsigned threads) {
+    if (tris.empty()) throw bvh_build_error("flatten: no triangles");
+    if (tris.size() >= (1u << 29)) throw bvh_build_error("flatten: too many triangles for the leaf reference encoding");
+    if (!ranks.empty() && ranks.size() != tris.size()) throw bvh_build_error("flatten: ranks/triangles size mismatch");
+
+    std::vector<int32_t> order;
+    const std::vector<sah_node> nodes = build_sah(tris, order, 4, threads);
+
+    // Inner nodes get their flat index in depth-first pre-order (a node's left subtree follows it).
+    std::vector<int32_t> flat_index(nodes.size(), -1);
+    std::vector<uint32_t> leaf_first(nodes.size(), 0);
+    uint32_t inner_count = 0, tri_cursor = 0, max_depth = 0;
+    {
+        struct visit { uint32_t id, depth; };
+        std::vector<visit> stack{ { 0, 0 } };
+        while (!stack.empty()) {
+            const visit v = stack.back();
+            stack.pop_back();
+            const sah_node& nd = nodes[v.id];
+            if (nd.left < 0) {
+                leaf_first[v.id] = tri_cursor;
+                tri_cursor += nd.count;
+                continue;
+            }
+            flat_index[v.id] = (int32_t)inner_count++;
+            max_depth = std::max(max_depth, v.depth + 1);
+            stack.push_back({ (uint32_t)nd.right, v.depth + 1 });
+            stack.push_back({ (uint32_t)nd.left, v.depth + 1 });
+        }
+    }
+    if (max_depth > FLAT_BVH_MAX_DEPTH) throw bvh_build_error("flatten: tree deeper than the traversal stack");
+
+    const size_t nodes_bytes = (size_t)inner_count * sizeof(flat_bvh_node);
+    const size_t tris_bytes = tris.size() * sizeof(flat_bvh_triangle);
+    std::vector<uint8_t> blob(sizeof(flat_bvh_header) + nodes_bytes + tris_bytes, 0);
+    auto* header = reinterpret_cast<flat_bvh_header*>(blob.data());
+    auto* out_nodes = reinterpret_cast<flat_bvh_node*>(blob.data() + sizeof(flat_bvh_header));
+    auto* out_tris = reinterpret_cast<flat_bvh_triangle*>(blob.data() + sizeof(flat_bvh_header) + nodes_bytes);
+
+    auto reference_to = [&](int32_t id) -> int32_t {
+        const sah_node& nd = nodes[id];
+        if (nd.left >= 0) return flat_index[id];
+        return ~(int32_t)((leaf_first[id] << 2) | (nd.count - 1));
+    };
+    for (size_t id = 0; id < nodes.size(); id++) {
+        const sah_node& nd = nodes[id];
+        if (nd.left < 0) {
+            for (uint32_t k = 0; k < nd.count; k++) {
+                const int32_t prim = order[nd.first + k];
+                fill_flat_triangle(out_tris[leaf_first[id] + k], tris[prim], prim, ranks.empty() ? prim : ranks[prim]);
+            }
+            continue;
+        }
+        flat_bvh_node& fn = out_nodes[flat_index[id]];
+        const aabb& lb = nodes[nd.left].box;
+        const aabb& rb = nodes[nd.right].box;
+        for (int a = 0; a < 3; a++) {
+            fn.lmin[a] = lb.minimum.v[a]; fn.lmax[a] = lb.maximum.v[a];
+            fn.rmin[a] = rb.minimum.v[a]; fn.rmax[a] = rb.maximum.v[a];
+        }
+        fn.left = reference_to(nd.left);
+        fn.right = reference_to(nd.right);
+        fn.pad0 = fn.pad1 = 0;
+    }
+
+    header->magic = FLAT_BVH_MAGIC;
+    header->version = 1;
+    header->node_count = inner_count;
+    header->triangle_count = (uint32_t)tris.size();
+    header->nodes_offset = sizeof(flat_bvh_header);
+    header->triangles_offset = sizeof(flat_bvh_header) + nodes_bytes;
+    header->root = reference_to(0);
+    header->max_depth = max_depth;
+    for (int a = 0; a < 3; a++) { header->scene_min[a] = nodes[0].box.minimum.v[a]; header->scene_max[a] = nodes[0].box.maximum.v[a]; }
+    return blob;
+}

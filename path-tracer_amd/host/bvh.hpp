@@ -1,0 +1,101 @@
+// BVH builder: keeps the reference's public API (include/bvh.hpp:9-60 in the reference:
+// `bvh(std::vector<triangle>&, std::vector<packed_bvh_node>&)`, `packed_bvh_node`, `exporter()`)
+// and adds what the MI355X kernels need:
+//   * build_mode::reference_order  -- the reference's top-down bucketed build (src/bvh.cpp:150-262),
+//     reproduced bit for bit: same threaded 32-byte node array, same depth-first numbering.
+//   * build_mode::sah_partitioned  -- a real binned-SAH build (primitives ARE partitioned).
+//   * flatten()                    -- the GPU layout: 64-byte, cache-line-aligned nodes that hold
+//     both children's boxes, and 64-byte pre-gathered triangle records in leaf order.
+#ifndef PTR_BVH_HPP_
+#define PTR_BVH_HPP_
+
+#include <cstdint>
+#include <stdexcept>
+#include <vector>
+
+#include "aabb.hpp"
+#include "triangle.hpp"
+
+// Threaded (skip-link) node, the layout the reference shader walks (compute.comp:60-65):
+// depth-first order, left child = id + 1, next_id = where to go on a miss (-1 = done).
+struct packed_bvh_node {
+    float min[3];
+    int32_t next_id = -1;
+    float max[3];
+    int32_t primitive_id = -1;
+};
+static_assert(sizeof(packed_bvh_node) == 32, "threaded node is 32 bytes");
+
+// ---- GPU layout -------------------------------------------------------------------------------
+// One 64-byte line per inner node.  A child reference >= 0 is an inner-node index; < 0 is a leaf:
+// ~ref = (first_triangle << 2) | (triangle_count - 1), 1..4 triangles per leaf.
+struct flat_bvh_node {
+    float lmin[3]; int32_t left;
+    float lmax[3]; int32_t right;
+    float rmin[3]; int32_t pad0;
+    float rmax[3]; int32_t pad1;
+};
+static_assert(sizeof(flat_bvh_node) == 64, "flat node is one 64-byte line");
+
+// One 64-byte line per triangle, in leaf order.  e1, e2 and n are the ray-independent terms of the
+// reference's intersection test (ray.h:142-146): e1 = p2 - p1, e2 = p3 - p1, n = cross(e1, e2),
+// computed here in fp32 with the shader's operation order so the kernel's u, v, t keep their bits.
+// `rank` is the triangle's position in the reference traversal order (tie-break on equal t:
+// the reference keeps the later-visited triangle, ray.h:153).
+struct flat_bvh_triangle {
+    float p0[3]; int32_t rank;
+    float e1[3]; int32_t primitive_id;
+    float e2[3]; int32_t pad0;
+    float n[3];  int32_t pad1;
+};
+static_assert(sizeof(flat_bvh_triangle) == 64, "flat triangle is one 64-byte line");
+
+struct flat_bvh_header {
+    uint32_t magic;            // 'PTRF'
+    uint32_t version;
+    uint32_t node_count;
+    uint32_t triangle_count;
+    uint64_t nodes_offset;     // byte offsets from the start of the blob, 64-byte aligned
+    uint64_t triangles_offset;
+    int32_t root;              // root reference (a leaf reference when the scene has <= 4 triangles)
+    uint32_t max_depth;        // deepest inner-node chain, bounds the traversal stack
+    float scene_min[3];
+    float scene_max[3];
+};
+static_assert(sizeof(flat_bvh_header) == 64, "header is one 64-byte line");
+
+constexpr uint32_t FLAT_BVH_MAGIC = 0x46525450u;  // "PTRF"
+constexpr uint32_t FLAT_BVH_MAX_DEPTH = 62;       // traversal stack capacity in the kernels
+
+class bvh_build_error : public std::runtime_error {
+public:
+    using std::runtime_error::runtime_error;
+};
+
+class bvh {
+public:
+    enum class build_mode { reference_order, sah_partitioned };
+
+    // Reference API.  Throws bvh_build_error where the reference would recurse without end
+    // (all centroids of a >4-triangle range equal on the split axis, src/bvh.cpp:208-216).
+    bvh(std::vector<triangle>& triangles, std::vector<packed_bvh_node>& packed_nodes);
+    bvh(std::vector<triangle>& triangles, std::vector<packed_bvh_node>& packed_nodes, build_mode mode);
+
+    // Graphviz dump of the threaded tree (the reference's debugging aid, src/bvh.cpp:91-99).
+    void exporter();
+
+    // Position of every primitive in the threaded tree's leaf visiting order.
+    static std::vector<int32_t> visit_ranks(const std::vector<packed_bvh_node>& packed_nodes, size_t primitive_count);
+
+    // GPU layout.  `ranks` (one per primitive) may be empty: then rank = primitive index.
+    // Returns one contiguous blob: header | nodes | triangles.
+    static std::vector<uint8_t> flatten(const std::vector<triangle>& triangles, const std::vector<int32_t>& ranks,
+                                        unsigned threads = 0);
+
+    std::vector<triangle>& triangles;
+
+private:
+    const std::vector<packed_bvh_node>* packed = nullptr;
+};
+
+#endif  // PTR_BVH_HPP_
