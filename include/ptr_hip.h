@@ -1,0 +1,113 @@
+/* C ABI of the MI355X render hot path (libptr_hip.so).
+ *
+ * This is the boundary the reference's compute renderpass would bind instead of Vulkan: every entry
+ * point replaces one piece of the reference's renderer interface for the `compute.comp` /
+ * `tonemapping.comp` dispatch path (citations are files of the reference repository).  Plain pointers,
+ * sizes and integer handles only; every call returns 0 on success or a negative PTR_E_* code
+ * (ptr_last_error() gives the text).  A context is bound to one GPU and is NOT thread-safe, like the
+ * reference's single-threaded renderer (include/vk-api.hpp:212-214 keeps plain vectors, no locks).
+ */
+#ifndef PTR_HIP_H_
+#define PTR_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ptr_ctx ptr_ctx;
+typedef uint32_t ptr_handle; /* 0 is never a valid handle */
+
+enum {
+    PTR_OK = 0,
+    PTR_E_INVALID = -1,     /* bad argument / unknown handle / unknown kernel name */
+    PTR_E_HIP = -2,         /* a HIP runtime call failed */
+    PTR_E_RANGE = -3,       /* offset/size outside the resource */
+    PTR_E_UNSUPPORTED = -4, /* format / sampler mode the path does not implement */
+    PTR_E_STATE = -5        /* e.g. a dispatch whose constant block names no registered resource */
+};
+
+/* image formats (the two the path uses: VK_FORMAT_R8G8B8A8_UNORM textures, src/gltf.cpp:126,151;
+ * VK_FORMAT_R32G32B32A32_SFLOAT accumulation/output images, src/main.cpp:261-262) */
+enum { PTR_FORMAT_RGBA8_UNORM = 37, PTR_FORMAT_RGBA32_SFLOAT = 109 }; /* numeric values = VkFormat */
+/* sampler state (VkFilter / VkSamplerAddressMode values); the path implements LINEAR + REPEAT, the only
+ * sampler the reference creates (src/gltf.cpp:118, src/vk-api.cpp:406-424) */
+enum { PTR_FILTER_NEAREST = 0, PTR_FILTER_LINEAR = 1 };
+enum { PTR_ADDRESS_REPEAT = 0, PTR_ADDRESS_CLAMP_TO_EDGE = 2 };
+
+/* ---- context: replaces the vkcontext/vkapi singletons (src/vk-renderer.cpp:21-23, src/vk-context.cpp:147-199) ---- */
+int ptr_ctx_create(int device, ptr_ctx** out);
+int ptr_ctx_destroy(ptr_ctx* ctx);
+/* Launch on a caller-owned hipStream_t (NULL = the context's own stream). */
+int ptr_ctx_set_stream(ptr_ctx* ctx, void* hip_stream);
+/* Text of the last error on this context (or of context creation when ctx is NULL). */
+const char* ptr_last_error(const ptr_ctx* ctx);
+/* Blocks until everything enqueued on the context's stream has finished (vkrenderer::begin_frame's
+ * fence wait, src/vk-renderer.cpp:214-221). */
+int ptr_sync(ptr_ctx* ctx);
+
+/* ---- buffers: vkrenderer::create_buffer + Buffer::write (src/vk-renderer.cpp:140-142,248-261) and the
+ *      device address the renderpass pushes (src/compute-renderpass.cpp:46-49) ---- */
+int ptr_buffer_create(ptr_ctx* ctx, size_t size, ptr_handle* out);
+int ptr_buffer_destroy(ptr_ctx* ctx, ptr_handle buffer);
+int ptr_buffer_write(ptr_ctx* ctx, ptr_handle buffer, const void* data, size_t offset, size_t size);
+int ptr_buffer_read(ptr_ctx* ctx, ptr_handle buffer, void* dst, size_t offset, size_t size);
+int ptr_buffer_address(ptr_ctx* ctx, ptr_handle buffer, uint64_t* device_address);
+
+/* ---- samplers and images: vkrenderer::create_sampler / create_2d_texture / Texture::update
+ *      (include/vk-renderer.hpp:64-66,166-228) and the bindless indices of vkapi (include/vk-api.hpp:72-86).
+ *      Index 0 is "no texture": sampling it yields opaque white. ---- */
+int ptr_sampler_create(ptr_ctx* ctx, int filter, int address_mode, ptr_handle* out);
+int ptr_image_create(ptr_ctx* ctx, uint32_t width, uint32_t height, int format, ptr_handle sampler, ptr_handle* out);
+/* Same, over device memory the caller owns (width*height*texel bytes, 16-byte aligned); never freed by the library. */
+int ptr_image_wrap(ptr_ctx* ctx, void* device_memory, uint32_t width, uint32_t height, int format, ptr_handle* out);
+int ptr_image_destroy(ptr_ctx* ctx, ptr_handle image);
+int ptr_image_upload(ptr_ctx* ctx, ptr_handle image, const void* texels);  /* whole image, host memory */
+int ptr_image_read(ptr_ctx* ctx, ptr_handle image, void* texels);          /* whole image, host memory */
+int ptr_image_index(ptr_ctx* ctx, ptr_handle image, uint32_t* bindless_index);
+int ptr_sampler_index(ptr_ctx* ctx, ptr_handle sampler, uint32_t* bindless_index);
+int ptr_image_address(ptr_ctx* ctx, ptr_handle image, uint64_t* device_address);
+
+/* ---- acceleration layout: associates the flattened, cache-line-aligned BVH blob emitted by
+ *      bvh::flatten() (a buffer holding header|nodes|triangles) with the threaded node buffer the
+ *      constant block names at offset 8.  A later "compute" dispatch on that node buffer then runs
+ *      the wavefront kernels over the flattened layout.  flat = 0 removes the association. ---- */
+int ptr_bvh_bind_flat(ptr_ctx* ctx, ptr_handle threaded_nodes, ptr_handle flat);
+
+/* ---- dispatch: ComputeRenderpass::execute -> vkCmdPushConstants(64 B) + vkCmdDispatch
+ *      (src/compute-renderpass.cpp:51-63, src/vk-api.cpp:1090-1092,1171-1177).
+ *      kernel: the reference's shader names, "compute" (shaders/compute.comp) or "tonemapping"
+ *      (shaders/tonemapping.comp).  "compute" picks the wavefront path when a flattened layout is
+ *      bound to the node buffer and the megakernel over the threaded nodes otherwise;
+ *      "compute.megakernel" / "compute.wavefront" force one.
+ *      constants: the 64-byte push-constant block (compute.comp:109-120): seven device addresses at
+ *      0,8,...,48 (scene, bvh, indices, positions, normals, uvs, materials), output image index at 56,
+ *      accumulation image index at 60.  groups_*: counts of 8x8x1 workgroups. ---- */
+int ptr_dispatch(ptr_ctx* ctx, const char* kernel, const uint8_t constants[64], uint32_t groups_x, uint32_t groups_y,
+                 uint32_t groups_z);
+
+/* ---- multi-GPU tile partition (no counterpart in the single-GPU reference): this context renders only
+ *      the 8-row-aligned stripes s with s % world == rank, stripe = stripe_rows image rows.
+ *      world = 1 restores the whole frame. ---- */
+int ptr_set_partition(ptr_ctx* ctx, uint32_t rank, uint32_t world, uint32_t stripe_rows);
+
+/* ---- instrumentation (no counterpart in the reference) ---- */
+/* Per-pixel capture of the first two closest hits of the next "compute" dispatches: 16 bytes per pixel
+ * {int32 prim0, float t0, int32 prim1, float t1}, prim = -1 for a miss / ended path.  0 = off. */
+int ptr_set_capture(ptr_ctx* ctx, ptr_handle buffer);
+/* Traversal counters: when on, "compute" dispatches run counting kernel variants.
+ * out[0..4] = rays, node records fetched, triangle records fetched, shaded hits, frames. */
+int ptr_stats_enable(ptr_ctx* ctx, int on);
+int ptr_stats_read(ptr_ctx* ctx, uint64_t out[8], int reset);
+/* Per-kernel device time from HIP events recorded around every launch on the context's stream. */
+int ptr_profile_enable(ptr_ctx* ctx, int on);
+int ptr_profile_read(ptr_ctx* ctx, const char* kernel_name, uint64_t* launches, double* total_ms, int reset);
+/* Names the profiler knows, '\n'-separated, into dst (size bytes incl. NUL). */
+int ptr_profile_names(ptr_ctx* ctx, char* dst, size_t size);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PTR_HIP_H_ */

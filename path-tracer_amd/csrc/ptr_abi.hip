@@ -1,0 +1,633 @@
+// C ABI of the render hot path (declared in include/ptr_hip.h): context, device resources, bindless
+// tables and the dispatch that turns the reference's 64-byte constant block into HIP launches.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/ptr_hip.h"
+#include "ptr_kernels.h"
+
+namespace {
+
+constexpr uint32_t kMaxImages = 4096;
+constexpr size_t kShadowLimit = 4096;  // buffers up to this size keep a host copy (the 160-byte metadata)
+
+struct BufferRec {
+    void* ptr = nullptr;
+    size_t size = 0;
+    bool alive = false;
+    ptr_handle flat = 0;  // flattened-layout buffer bound to this (threaded node) buffer
+    std::vector<uint8_t> shadow;
+    bool flat_view_valid = false;  // this buffer holds a flattened layout whose header was parsed
+    ptr::FlatView flat_view{};
+};
+struct ImageRec {
+    void* ptr = nullptr;
+    uint32_t w = 0, h = 0;
+    int format = 0;
+    uint32_t sampler = 0;
+    bool owned = false, alive = false;
+};
+struct SamplerRec { int filter = 0, address = 0; bool alive = false; };
+
+struct ProfileRec {
+    uint64_t launches = 0;
+    double total_ms = 0.0;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+};
+
+thread_local std::string g_create_error;
+
+}  // namespace
+
+struct ptr_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipStream_t own_stream = nullptr;
+    std::string error;
+    std::vector<BufferRec> buffers{ 1 };    // index = handle; 0 unused
+    std::vector<ImageRec> images{ 1 };      // index = handle = bindless index
+    std::vector<SamplerRec> samplers{ 1 };
+    ptr::ImageDesc* d_images = nullptr;     // device copy of the bindless image table
+    uint32_t part_rank = 0, part_world = 1, part_stripe = 8;
+    ptr_handle capture = 0;
+    bool stats_on = false;
+    unsigned long long* d_stats = nullptr;  // 8 counters
+    uint64_t stats_frames = 0;
+    bool profile_on = false;
+    std::map<std::string, ProfileRec> profile;
+    std::vector<hipEvent_t> event_pool;
+    ptr::WavefrontScratch scratch{};
+    void* scratch_block = nullptr;
+    int cu_count = 256;
+};
+
+namespace {
+
+int fail(ptr_ctx* c, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (c) c->error = buf; else g_create_error = buf;
+    return code;
+}
+
+#define PTR_HIP_CHECK(ctx, expr)                                                                       \
+    do {                                                                                               \
+        hipError_t e_ = (expr);                                                                        \
+        if (e_ != hipSuccess) return fail(ctx, PTR_E_HIP, "%s: %s", #expr, hipGetErrorString(e_));     \
+    } while (0)
+
+int bind_device(ptr_ctx* c) {
+    PTR_HIP_CHECK(c, hipSetDevice(c->device));
+    return PTR_OK;
+}
+
+BufferRec* find_buffer(ptr_ctx* c, ptr_handle h) {
+    if (h == 0 || h >= c->buffers.size() || !c->buffers[h].alive) return nullptr;
+    return &c->buffers[h];
+}
+ImageRec* find_image(ptr_ctx* c, ptr_handle h) {
+    if (h == 0 || h >= c->images.size() || !c->images[h].alive) return nullptr;
+    return &c->images[h];
+}
+size_t texel_size(int format) { return format == PTR_FORMAT_RGBA8_UNORM ? 4 : (format == PTR_FORMAT_RGBA32_SFLOAT ? 16 : 0); }
+
+// The registered buffer that contains [addr, addr + need), or null.
+BufferRec* buffer_at(ptr_ctx* c, uint64_t addr, size_t need, ptr_handle* handle = nullptr) {
+    for (size_t i = 1; i < c->buffers.size(); i++) {
+        BufferRec& b = c->buffers[i];
+        if (!b.alive) continue;
+        const uint64_t base = (uint64_t)(uintptr_t)b.ptr;
+        if (addr >= base && addr + need <= base + b.size) {
+            if (handle) *handle = (ptr_handle)i;
+            return &b;
+        }
+    }
+    return nullptr;
+}
+
+int upload_image_desc(ptr_ctx* c, ptr_handle h) {
+    const ImageRec& r = c->images[h];
+    ptr::ImageDesc d;
+    d.data = r.alive ? r.ptr : nullptr;
+    d.width = r.w; d.height = r.h; d.format = (uint32_t)r.format; d.sampler = r.sampler;
+    PTR_HIP_CHECK(c, hipMemcpyAsync(c->d_images + h, &d, sizeof d, hipMemcpyHostToDevice, c->stream));
+    // the descriptor lives on the stack: finish the copy before returning
+    PTR_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+    return PTR_OK;
+}
+
+// ---- profiling: events around a launch ----
+hipEvent_t take_event(ptr_ctx* c) {
+    if (!c->event_pool.empty()) { hipEvent_t e = c->event_pool.back(); c->event_pool.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    return e;
+}
+struct ScopedProfile {
+    ptr_ctx* c; const char* name; hipEvent_t start = nullptr, stop = nullptr;
+    ScopedProfile(ptr_ctx* ctx, const char* n) : c(ctx), name(n) {
+        if (!c->profile_on) return;
+        start = take_event(c); stop = take_event(c);
+        if (start && stop) (void)hipEventRecord(start, c->stream);
+    }
+    ~ScopedProfile() {
+        if (!c->profile_on || !start || !stop) return;
+        (void)hipEventRecord(stop, c->stream);
+        c->profile[name].pending.emplace_back(start, stop);
+    }
+};
+void drain_profile(ptr_ctx* c) {
+    for (auto& kv : c->profile) {
+        for (auto& p : kv.second.pending) {
+            float ms = 0.f;
+            if (hipEventSynchronize(p.second) == hipSuccess && hipEventElapsedTime(&ms, p.first, p.second) == hipSuccess) {
+                kv.second.launches++;
+                kv.second.total_ms += ms;
+            }
+            c->event_pool.push_back(p.first);
+            c->event_pool.push_back(p.second);
+        }
+        kv.second.pending.clear();
+    }
+}
+
+// ---- wavefront scratch ----
+int ensure_scratch(ptr_ctx* c, uint32_t capacity) {
+    if (c->scratch.capacity >= capacity && c->scratch_block) return PTR_OK;
+    if (c->scratch_block) { PTR_HIP_CHECK(c, hipStreamSynchronize(c->stream)); PTR_HIP_CHECK(c, hipFree(c->scratch_block)); c->scratch_block = nullptr; }
+    const size_t cap = ((size_t)capacity + 255) & ~(size_t)255;
+    const uint32_t extend_blocks = (uint32_t)c->cu_count * 4u;
+    const size_t spill_words = (size_t)extend_blocks * (ptr::kExtendThreads / 64) * ptr::kStackSpill * 64;
+    // 2 generations x (6 ray + 3 throughput + seed + pixel) words, hits + samples (4 words each), counters, spill
+    const size_t words = cap * (2 * 11 + 8) + 64 + spill_words;
+    PTR_HIP_CHECK(c, hipMalloc(&c->scratch_block, words * 4));
+    uint32_t* p = (uint32_t*)c->scratch_block;
+    auto take = [&](size_t n) { uint32_t* r = p; p += n; return r; };
+    ptr::WavefrontScratch& s = c->scratch;
+    s.hits = (float4*)take(cap * 4);
+    s.samples = (float4*)take(cap * 4);
+    for (int g = 0; g < 2; g++) {
+        for (int k = 0; k < 6; k++) s.ray[g][k] = (float*)take(cap);
+        for (int k = 0; k < 3; k++) s.throughput[g][k] = (float*)take(cap);
+        s.seed[g] = take(cap);
+        s.pixel[g] = take(cap);
+    }
+    s.counters = take(64);
+    s.stack_spill = (int32_t*)take(spill_words);
+    s.capacity = (uint32_t)cap;
+    s.extend_blocks = extend_blocks;
+    return PTR_OK;
+}
+
+struct ParsedConstants {
+    uint64_t addr[7];
+    uint32_t output_index, accumulation_index;
+};
+ParsedConstants parse_constants(const uint8_t* k) {
+    ParsedConstants p;
+    memcpy(p.addr, k, 56);
+    memcpy(&p.output_index, k + 56, 4);
+    memcpy(&p.accumulation_index, k + 60, 4);
+    return p;
+}
+
+// Host view of the 160-byte metadata the constant block points at.
+int read_meta(ptr_ctx* c, uint64_t addr, ptr::SceneMeta* out) {
+    ptr_handle h = 0;
+    BufferRec* b = buffer_at(c, addr, sizeof(ptr::SceneMeta), &h);
+    if (!b) return fail(c, PTR_E_STATE, "constant block: scene metadata address is not inside a registered buffer");
+    const size_t off = (size_t)(addr - (uint64_t)(uintptr_t)b->ptr);
+    if (!b->shadow.empty()) { memcpy(out, b->shadow.data() + off, sizeof *out); return PTR_OK; }
+    PTR_HIP_CHECK(c, hipMemcpyAsync(out, (const uint8_t*)b->ptr + off, sizeof *out, hipMemcpyDeviceToHost, c->stream));
+    PTR_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+    return PTR_OK;
+}
+
+int check_storage_image(ptr_ctx* c, uint32_t index, const char* what) {
+    ImageRec* im = find_image(c, index);
+    if (!im) return fail(c, PTR_E_STATE, "constant block: %s image index %u is not a live image", what, index);
+    if (im->format != PTR_FORMAT_RGBA32_SFLOAT) return fail(c, PTR_E_STATE, "constant block: %s image must be RGBA32_SFLOAT", what);
+    return PTR_OK;
+}
+
+int dispatch_compute(ptr_ctx* c, const uint8_t constants[64], uint32_t gx, uint32_t gy, int force /*0 auto,1 mega,2 wavefront*/) {
+    const ParsedConstants k = parse_constants(constants);
+    ptr::SceneMeta meta;
+    int rc = read_meta(c, k.addr[0], &meta);
+    if (rc) return rc;
+    if (meta.width == 0 || meta.height == 0) return fail(c, PTR_E_STATE, "scene metadata: zero width/height");
+    if (meta.downscale_factor < 1) return fail(c, PTR_E_STATE, "scene metadata: downscale_factor < 1");
+    if (meta.sample_index == 0) return fail(c, PTR_E_STATE, "scene metadata: sample_index must start at 1 (1/sample_index weights the frame)");
+
+    static const char* names[7] = { "scene", "bvh", "indices", "positions", "normals", "uvs", "materials" };
+    ptr_handle handles[7] = {};
+    for (int i = 1; i < 7; i++) {
+        if (!buffer_at(c, k.addr[i], 1, &handles[i])) return fail(c, PTR_E_STATE, "constant block: %s address is not inside a registered buffer", names[i]);
+    }
+    if ((rc = check_storage_image(c, k.output_index, "output"))) return rc;
+    if ((rc = check_storage_image(c, k.accumulation_index, "accumulation"))) return rc;
+
+    ptr::SceneView sv{};
+    sv.meta = (const ptr::SceneMeta*)(uintptr_t)k.addr[0];
+    sv.nodes = (const ptr::ThreadedNode*)(uintptr_t)k.addr[1];
+    sv.indices = (const uint32_t*)(uintptr_t)k.addr[2];
+    sv.positions = (const float*)(uintptr_t)k.addr[3];
+    sv.normals = (const float*)(uintptr_t)k.addr[4];
+    sv.uvs = (const float*)(uintptr_t)k.addr[5];
+    sv.materials = (const ptr::Material*)(uintptr_t)k.addr[6];
+    sv.images = c->d_images;
+    sv.image_count = (uint32_t)c->images.size();
+    sv.output_index = k.output_index;
+    sv.accumulation_index = k.accumulation_index;
+    sv.part_rank = c->part_rank; sv.part_world = c->part_world; sv.part_stripe_rows = c->part_stripe;
+    sv.capture = nullptr;
+    if (c->capture) {
+        BufferRec* cb = find_buffer(c, c->capture);
+        if (!cb || cb->size < (size_t)meta.width * meta.height * sizeof(ptr::Capture)) return fail(c, PTR_E_STATE, "capture buffer smaller than width*height*16 bytes");
+        sv.capture = (ptr::Capture*)cb->ptr;
+    }
+    sv.stats = c->stats_on ? c->d_stats : nullptr;
+
+    BufferRec* bvh_buf = &c->buffers[handles[1]];
+    BufferRec* flat_buf = bvh_buf->flat ? find_buffer(c, bvh_buf->flat) : nullptr;
+    const bool wavefront = force == 2 || (force == 0 && flat_buf != nullptr);
+    if (c->stats_on) c->stats_frames++;
+
+    if (!wavefront) {
+        // the threaded walk starts at node 0 and trusts the links: at least one node must be there
+        if (k.addr[1] + 32 > (uint64_t)(uintptr_t)bvh_buf->ptr + bvh_buf->size) return fail(c, PTR_E_STATE, "bvh buffer holds no node");
+        ScopedProfile prof(c, "compute.megakernel");
+        PTR_HIP_CHECK(c, ptr::launch_megakernel(c->stream, sv, gx, gy, c->stats_on));
+        return PTR_OK;
+    }
+
+    if (!flat_buf) return fail(c, PTR_E_STATE, "compute.wavefront: no flattened layout bound to the bvh buffer (ptr_bvh_bind_flat)");
+    if (!flat_buf->flat_view_valid) {  // parse + validate the header once per upload
+        struct Header { uint32_t magic, version, node_count, triangle_count; uint64_t nodes_offset, triangles_offset; int32_t root; uint32_t max_depth; float bounds[6]; } hd;
+        if (flat_buf->size < sizeof hd) return fail(c, PTR_E_STATE, "flattened layout: blob shorter than its header");
+        PTR_HIP_CHECK(c, hipMemcpyAsync(&hd, flat_buf->ptr, sizeof hd, hipMemcpyDeviceToHost, c->stream));
+        PTR_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+        if (hd.magic != 0x46525450u || hd.version != 1u) return fail(c, PTR_E_STATE, "flattened layout: bad magic/version");
+        if ((hd.nodes_offset & 63u) || (hd.triangles_offset & 63u)) return fail(c, PTR_E_STATE, "flattened layout: sections are not 64-byte aligned");
+        if (hd.nodes_offset + (uint64_t)hd.node_count * 64 > flat_buf->size || hd.triangles_offset + (uint64_t)hd.triangle_count * 64 > flat_buf->size)
+            return fail(c, PTR_E_STATE, "flattened layout: sections exceed the buffer");
+        if (hd.max_depth > ptr::kStackLds + ptr::kStackSpill - 2) return fail(c, PTR_E_STATE, "flattened layout: deeper than the traversal stack");
+        if (hd.root >= 0 ? (uint32_t)hd.root >= hd.node_count : ((uint32_t)~hd.root >> 2) + ((uint32_t)~hd.root & 3u) + 1u > hd.triangle_count)
+            return fail(c, PTR_E_STATE, "flattened layout: root reference out of range");
+        flat_buf->flat_view.nodes = (const float4*)((const uint8_t*)flat_buf->ptr + hd.nodes_offset);
+        flat_buf->flat_view.triangles = (const float4*)((const uint8_t*)flat_buf->ptr + hd.triangles_offset);
+        flat_buf->flat_view.root = hd.root;
+        flat_buf->flat_view.max_depth = hd.max_depth;
+        flat_buf->flat_view_valid = true;
+    }
+    const ptr::FlatView fv = flat_buf->flat_view;
+
+    const uint32_t domain_w = gx * 8u < meta.width ? gx * 8u : meta.width;
+    const uint32_t domain_h = gy * 8u < meta.height ? gy * 8u : meta.height;
+    if (domain_w == 0 || domain_h == 0) return PTR_OK;
+    if ((rc = ensure_scratch(c, meta.width * meta.height))) return rc;
+    const ptr::WavefrontScratch& w = c->scratch;
+
+    PTR_HIP_CHECK(c, hipMemsetAsync(w.counters, 0, 64 * sizeof(uint32_t), c->stream));
+    if (meta.max_bounce == 0) PTR_HIP_CHECK(c, hipMemsetAsync(w.samples, 0, (size_t)w.capacity * 16, c->stream));
+    { ScopedProfile prof(c, "wavefront.generate"); PTR_HIP_CHECK(c, ptr::launch_wf_generate(c->stream, sv, w, domain_w, domain_h)); }
+    for (uint32_t b = 0; b < meta.max_bounce; b++) {
+        if (b + 1 >= ptr::kMaxBounceSlots) {  // recycle the counter slots of a bounce that finished long ago
+            const uint32_t s = (b + 1) % ptr::kMaxBounceSlots;
+            PTR_HIP_CHECK(c, hipMemsetAsync(w.counters + s, 0, 4, c->stream));
+            PTR_HIP_CHECK(c, hipMemsetAsync(w.counters + ptr::kMaxBounceSlots + s, 0, 4, c->stream));
+        }
+        { ScopedProfile prof(c, "wavefront.extend"); PTR_HIP_CHECK(c, ptr::launch_wf_extend(c->stream, fv, w, b, sv.stats)); }
+        { ScopedProfile prof(c, "wavefront.shade"); PTR_HIP_CHECK(c, ptr::launch_wf_shade(c->stream, sv, w, b, meta.max_bounce, meta.min_bounce, domain_w, domain_h)); }
+    }
+    { ScopedProfile prof(c, "wavefront.accumulate"); PTR_HIP_CHECK(c, ptr::launch_wf_accumulate(c->stream, sv, w, domain_w, domain_h)); }
+    return PTR_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ptr_ctx_create(int device, ptr_ctx** out) {
+    if (!out) return fail(nullptr, PTR_E_INVALID, "ptr_ctx_create: out is null");
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count == 0) return fail(nullptr, PTR_E_HIP, "no HIP device: %s", hipGetErrorString(e));
+    if (device < 0 || device >= count) return fail(nullptr, PTR_E_INVALID, "device %d out of range (%d devices)", device, count);
+    ptr_ctx* c = new ptr_ctx();
+    c->device = device;
+    auto bail = [&](const char* what, hipError_t err) { fail(nullptr, PTR_E_HIP, "%s: %s", what, hipGetErrorString(err)); delete c; return PTR_E_HIP; };
+    if ((e = hipSetDevice(device)) != hipSuccess) return bail("hipSetDevice", e);
+    hipDeviceProp_t prop;
+    if ((e = hipGetDeviceProperties(&prop, device)) != hipSuccess) return bail("hipGetDeviceProperties", e);
+    c->cu_count = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if ((e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
+    c->stream = c->own_stream;
+    if ((e = hipMalloc((void**)&c->d_images, kMaxImages * sizeof(ptr::ImageDesc))) != hipSuccess) return bail("hipMalloc(image table)", e);
+    if ((e = hipMemset(c->d_images, 0, kMaxImages * sizeof(ptr::ImageDesc))) != hipSuccess) return bail("hipMemset(image table)", e);
+    if ((e = hipMalloc((void**)&c->d_stats, 8 * sizeof(unsigned long long))) != hipSuccess) return bail("hipMalloc(stats)", e);
+    if ((e = hipMemset(c->d_stats, 0, 8 * sizeof(unsigned long long))) != hipSuccess) return bail("hipMemset(stats)", e);
+    *out = c;
+    return PTR_OK;
+}
+
+int ptr_ctx_destroy(ptr_ctx* c) {
+    if (!c) return PTR_E_INVALID;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    drain_profile(c);
+    for (auto e : c->event_pool) (void)hipEventDestroy(e);
+    for (auto& b : c->buffers) if (b.alive && b.ptr) (void)hipFree(b.ptr);
+    for (auto& im : c->images) if (im.alive && im.owned && im.ptr) (void)hipFree(im.ptr);
+    if (c->scratch_block) (void)hipFree(c->scratch_block);
+    if (c->d_images) (void)hipFree(c->d_images);
+    if (c->d_stats) (void)hipFree(c->d_stats);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    delete c;
+    return PTR_OK;
+}
+
+int ptr_ctx_set_stream(ptr_ctx* c, void* hip_stream) {
+    if (!c) return PTR_E_INVALID;
+    int rc = bind_device(c); if (rc) return rc;
+    PTR_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+    c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+    return PTR_OK;
+}
+
+const char* ptr_last_error(const ptr_ctx* c) { return c ? c->error.c_str() : g_create_error.c_str(); }
+
+int ptr_sync(ptr_ctx* c) {
+    if (!c) return PTR_E_INVALID;
+    int rc = bind_device(c); if (rc) return rc;
+    PTR_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+    return PTR_OK;
+}
+
+int ptr_buffer_create(ptr_ctx* c, size_t size, ptr_handle* out) {
+    if (!c || !out) return PTR_E_INVALID;
+    if (size == 0) return fail(c, PTR_E_INVALID, "ptr_buffer_create: size 0");
+    int rc = bind_device(c); if (rc) return rc;
+    BufferRec b;
+    PTR_HIP_CHECK(c, hipMalloc(&b.ptr, size));
+    b.size = size; b.alive = true;
+    if (size <= kShadowLimit) b.shadow.assign(size, 0);
+    if (size <= kShadowLimit) PTR_HIP_CHECK(c, hipMemsetAsync(b.ptr, 0, size, c->stream));
+    c->buffers.push_back(std::move(b));
+    *out = (ptr_handle)(c->buffers.size() - 1);
+    return PTR_OK;
+}
+
+int ptr_buffer_destroy(ptr_ctx* c, ptr_handle h) {
+    if (!c) return PTR_E_INVALID;
+    BufferRec* b = find_buffer(c, h);
+    if (!b) return fail(c, PTR_E_INVALID, "ptr_buffer_destroy: unknown buffer %u", h);
+    int rc = bind_device(c); if (rc) return rc;
+    PTR_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+    PTR_HIP_CHECK(c, hipFree(b->ptr));
+    *b = BufferRec();
+    for (auto& o : c->buffers) if (o.flat == h) o.flat = 0;
+    if (c->capture == h) c->capture = 0;
+    return PTR_OK;
+}
+
+int ptr_buffer_write(ptr_ctx* c, ptr_handle h, const void* data, size_t offset, size_t size) {
+    if (!c) return PTR_E_INVALID;
+    BufferRec* b = find_buffer(c, h);
+    if (!b) return fail(c, PTR_E_INVALID, "ptr_buffer_write: unknown buffer %u", h);
+    if (!data && size) return fail(c, PTR_E_INVALID, "ptr_buffer_write: null data");
+    if (offset > b->size || size > b->size - offset) return fail(c, PTR_E_RANGE, "ptr_buffer_write: [%zu, +%zu) outside a %zu-byte buffer", offset, size, b->size);
+    if (size == 0) return PTR_OK;
+    int rc = bind_device(c); if (rc) return rc;
+    if (!b->shadow.empty()) memcpy(b->shadow.data() + offset, data, size);
+    b->flat_view_valid = false;
+    // Buffer::write is a memcpy into mapped memory in the reference: the caller may reuse `data` at once.
+    PTR_HIP_CHECK(c, hipMemcpyAsync((uint8_t*)b->ptr + offset, data, size, hipMemcpyHostToDevice, c->stream));
+    PTR_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+    return PTR_OK;
+}
+
+int ptr_buffer_read(ptr_ctx* c, ptr_handle h, void* dst, size_t offset, size_t size) {
+    if (!c) return PTR_E_INVALID;
+    BufferRec* b = find_buffer(c, h);
+    if (!b) return fail(c, PTR_E_INVALID, "ptr_buffer_read: unknown buffer %u", h);
+    if (!dst && size) return fail(c, PTR_E_INVALID, "ptr_buffer_read: null dst");
+    if (offset > b->size || size > b->size - offset) return fail(c, PTR_E_RANGE, "ptr_buffer_read: [%zu, +%zu) outside a %zu-byte buffer", offset, size, b->size);
+    if (size == 0) return PTR_OK;
+    int rc = bind_device(c); if (rc) return rc;
+    PTR_HIP_CHECK(c, hipMemcpyAsync(dst, (const uint8_t*)b->ptr + offset, size, hipMemcpyDeviceToHost, c->stream));
+    PTR_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+    return PTR_OK;
+}
+
+int ptr_buffer_address(ptr_ctx* c, ptr_handle h, uint64_t* addr) {
+    if (!c || !addr) return PTR_E_INVALID;
+    BufferRec* b = find_buffer(c, h);
+    if (!b) return fail(c, PTR_E_INVALID, "ptr_buffer_address: unknown buffer %u", h);
+    *addr = (uint64_t)(uintptr_t)b->ptr;
+    return PTR_OK;
+}
+
+int ptr_sampler_create(ptr_ctx* c, int filter, int address_mode, ptr_handle* out) {
+    if (!c || !out) return PTR_E_INVALID;
+    if (filter != PTR_FILTER_LINEAR || address_mode != PTR_ADDRESS_REPEAT)
+        return fail(c, PTR_E_UNSUPPORTED, "ptr_sampler_create: only LINEAR filtering with REPEAT addressing is implemented");
+    SamplerRec s; s.filter = filter; s.address = address_mode; s.alive = true;
+    c->samplers.push_back(s);
+    *out = (ptr_handle)(c->samplers.size() - 1);
+    return PTR_OK;
+}
+
+static int new_image(ptr_ctx* c, void* memory, bool owned, uint32_t w, uint32_t h, int format, ptr_handle sampler, ptr_handle* out) {
+    if (c->images.size() >= kMaxImages) { if (owned) (void)hipFree(memory); return fail(c, PTR_E_RANGE, "bindless image table is full (%u)", kMaxImages); }
+    ImageRec r; r.ptr = memory; r.w = w; r.h = h; r.format = format; r.sampler = sampler; r.owned = owned; r.alive = true;
+    c->images.push_back(r);
+    *out = (ptr_handle)(c->images.size() - 1);
+    return upload_image_desc(c, *out);
+}
+
+int ptr_image_create(ptr_ctx* c, uint32_t w, uint32_t h, int format, ptr_handle sampler, ptr_handle* out) {
+    if (!c || !out) return PTR_E_INVALID;
+    const size_t ts = texel_size(format);
+    if (ts == 0) return fail(c, PTR_E_UNSUPPORTED, "ptr_image_create: format %d (RGBA8_UNORM and RGBA32_SFLOAT are implemented)", format);
+    if (w == 0 || h == 0) return fail(c, PTR_E_INVALID, "ptr_image_create: zero extent");
+    if (sampler != 0 && (sampler >= c->samplers.size() || !c->samplers[sampler].alive)) return fail(c, PTR_E_INVALID, "ptr_image_create: unknown sampler %u", sampler);
+    int rc = bind_device(c); if (rc) return rc;
+    void* mem = nullptr;
+    PTR_HIP_CHECK(c, hipMalloc(&mem, (size_t)w * h * ts));
+    PTR_HIP_CHECK(c, hipMemsetAsync(mem, 0, (size_t)w * h * ts, c->stream));
+    return new_image(c, mem, true, w, h, format, sampler, out);
+}
+
+int ptr_image_wrap(ptr_ctx* c, void* device_memory, uint32_t w, uint32_t h, int format, ptr_handle* out) {
+    if (!c || !out) return PTR_E_INVALID;
+    if (texel_size(format) == 0) return fail(c, PTR_E_UNSUPPORTED, "ptr_image_wrap: format %d", format);
+    if (!device_memory || ((uintptr_t)device_memory & 15u)) return fail(c, PTR_E_INVALID, "ptr_image_wrap: memory must be non-null and 16-byte aligned");
+    if (w == 0 || h == 0) return fail(c, PTR_E_INVALID, "ptr_image_wrap: zero extent");
+    int rc = bind_device(c); if (rc) return rc;
+    return new_image(c, device_memory, false, w, h, format, 0, out);
+}
+
+int ptr_image_destroy(ptr_ctx* c, ptr_handle h) {
+    if (!c) return PTR_E_INVALID;
+    ImageRec* im = find_image(c, h);
+    if (!im) return fail(c, PTR_E_INVALID, "ptr_image_destroy: unknown image %u", h);
+    int rc = bind_device(c); if (rc) return rc;
+    PTR_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+    if (im->owned) PTR_HIP_CHECK(c, hipFree(im->ptr));
+    *im = ImageRec();
+    return upload_image_desc(c, h);
+}
+
+int ptr_image_upload(ptr_ctx* c, ptr_handle h, const void* texels) {
+    if (!c) return PTR_E_INVALID;
+    ImageRec* im = find_image(c, h);
+    if (!im) return fail(c, PTR_E_INVALID, "ptr_image_upload: unknown image %u", h);
+    if (!texels) return fail(c, PTR_E_INVALID, "ptr_image_upload: null texels");
+    int rc = bind_device(c); if (rc) return rc;
+    PTR_HIP_CHECK(c, hipMemcpyAsync(im->ptr, texels, (size_t)im->w * im->h * texel_size(im->format), hipMemcpyHostToDevice, c->stream));
+    PTR_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+    return PTR_OK;
+}
+
+int ptr_image_read(ptr_ctx* c, ptr_handle h, void* texels) {
+    if (!c) return PTR_E_INVALID;
+    ImageRec* im = find_image(c, h);
+    if (!im) return fail(c, PTR_E_INVALID, "ptr_image_read: unknown image %u", h);
+    if (!texels) return fail(c, PTR_E_INVALID, "ptr_image_read: null texels");
+    int rc = bind_device(c); if (rc) return rc;
+    PTR_HIP_CHECK(c, hipMemcpyAsync(texels, im->ptr, (size_t)im->w * im->h * texel_size(im->format), hipMemcpyDeviceToHost, c->stream));
+    PTR_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+    return PTR_OK;
+}
+
+int ptr_image_index(ptr_ctx* c, ptr_handle h, uint32_t* index) {
+    if (!c || !index) return PTR_E_INVALID;
+    if (!find_image(c, h)) return fail(c, PTR_E_INVALID, "ptr_image_index: unknown image %u", h);
+    *index = h;
+    return PTR_OK;
+}
+
+int ptr_sampler_index(ptr_ctx* c, ptr_handle h, uint32_t* index) {
+    if (!c || !index) return PTR_E_INVALID;
+    if (h == 0 || h >= c->samplers.size() || !c->samplers[h].alive) return fail(c, PTR_E_INVALID, "ptr_sampler_index: unknown sampler %u", h);
+    *index = h;
+    return PTR_OK;
+}
+
+int ptr_image_address(ptr_ctx* c, ptr_handle h, uint64_t* addr) {
+    if (!c || !addr) return PTR_E_INVALID;
+    ImageRec* im = find_image(c, h);
+    if (!im) return fail(c, PTR_E_INVALID, "ptr_image_address: unknown image %u", h);
+    *addr = (uint64_t)(uintptr_t)im->ptr;
+    return PTR_OK;
+}
+
+int ptr_bvh_bind_flat(ptr_ctx* c, ptr_handle threaded_nodes, ptr_handle flat) {
+    if (!c) return PTR_E_INVALID;
+    BufferRec* b = find_buffer(c, threaded_nodes);
+    if (!b) return fail(c, PTR_E_INVALID, "ptr_bvh_bind_flat: unknown node buffer %u", threaded_nodes);
+    if (flat != 0) {
+        BufferRec* f = find_buffer(c, flat);
+        if (!f) return fail(c, PTR_E_INVALID, "ptr_bvh_bind_flat: unknown flat buffer %u", flat);
+        if (f->size < 64) return fail(c, PTR_E_INVALID, "ptr_bvh_bind_flat: flat buffer shorter than the 64-byte header");
+    }
+    b->flat = flat;
+    return PTR_OK;
+}
+
+int ptr_dispatch(ptr_ctx* c, const char* kernel, const uint8_t constants[64], uint32_t gx, uint32_t gy, uint32_t gz) {
+    if (!c) return PTR_E_INVALID;
+    if (!kernel || !constants) return fail(c, PTR_E_INVALID, "ptr_dispatch: null kernel name or constants");
+    int rc = bind_device(c); if (rc) return rc;
+    if (gx == 0 || gy == 0 || gz == 0) return PTR_OK;
+    if ((uint64_t)gx * gy > 0x7fffffffull) return fail(c, PTR_E_RANGE, "ptr_dispatch: too many workgroups");
+    // the shaders only read gl_GlobalInvocationID.xy: z slices would repeat the same work, one slice is run
+    if (!strcmp(kernel, "compute")) return dispatch_compute(c, constants, gx, gy, 0);
+    if (!strcmp(kernel, "compute.megakernel")) return dispatch_compute(c, constants, gx, gy, 1);
+    if (!strcmp(kernel, "compute.wavefront")) return dispatch_compute(c, constants, gx, gy, 2);
+    if (!strcmp(kernel, "tonemapping")) {
+        const ParsedConstants k = parse_constants(constants);
+        if (!buffer_at(c, k.addr[0], sizeof(ptr::SceneMeta))) return fail(c, PTR_E_STATE, "constant block: scene metadata address is not inside a registered buffer");
+        if ((rc = check_storage_image(c, k.output_index, "output"))) return rc;
+        if ((rc = check_storage_image(c, k.accumulation_index, "accumulation"))) return rc;
+        ScopedProfile prof(c, "tonemapping");
+        PTR_HIP_CHECK(c, ptr::launch_tonemap(c->stream, (const ptr::SceneMeta*)(uintptr_t)k.addr[0], c->d_images, (uint32_t)c->images.size(),
+                                             k.output_index, k.accumulation_index, gx, gy));
+        return PTR_OK;
+    }
+    return fail(c, PTR_E_INVALID, "ptr_dispatch: unknown kernel '%s' (compute, compute.megakernel, compute.wavefront, tonemapping)", kernel);
+}
+
+int ptr_set_partition(ptr_ctx* c, uint32_t rank, uint32_t world, uint32_t stripe_rows) {
+    if (!c) return PTR_E_INVALID;
+    if (world == 0 || rank >= world) return fail(c, PTR_E_INVALID, "ptr_set_partition: rank %u / world %u", rank, world);
+    if (stripe_rows == 0 || (stripe_rows & 7u)) return fail(c, PTR_E_INVALID, "ptr_set_partition: stripe_rows must be a positive multiple of 8");
+    c->part_rank = rank; c->part_world = world; c->part_stripe = stripe_rows;
+    return PTR_OK;
+}
+
+int ptr_set_capture(ptr_ctx* c, ptr_handle buffer) {
+    if (!c) return PTR_E_INVALID;
+    if (buffer != 0 && !find_buffer(c, buffer)) return fail(c, PTR_E_INVALID, "ptr_set_capture: unknown buffer %u", buffer);
+    c->capture = buffer;
+    return PTR_OK;
+}
+
+int ptr_stats_enable(ptr_ctx* c, int on) {
+    if (!c) return PTR_E_INVALID;
+    c->stats_on = on != 0;
+    return PTR_OK;
+}
+
+int ptr_stats_read(ptr_ctx* c, uint64_t out[8], int reset) {
+    if (!c || !out) return PTR_E_INVALID;
+    int rc = bind_device(c); if (rc) return rc;
+    unsigned long long host[8];
+    PTR_HIP_CHECK(c, hipMemcpyAsync(host, c->d_stats, sizeof host, hipMemcpyDeviceToHost, c->stream));
+    PTR_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+    for (int i = 0; i < 8; i++) out[i] = host[i];
+    out[4] = c->stats_frames;
+    if (reset) {
+        PTR_HIP_CHECK(c, hipMemsetAsync(c->d_stats, 0, sizeof host, c->stream));
+        c->stats_frames = 0;
+    }
+    return PTR_OK;
+}
+
+int ptr_profile_enable(ptr_ctx* c, int on) {
+    if (!c) return PTR_E_INVALID;
+    c->profile_on = on != 0;
+    return PTR_OK;
+}
+
+int ptr_profile_read(ptr_ctx* c, const char* name, uint64_t* launches, double* total_ms, int reset) {
+    if (!c || !name) return PTR_E_INVALID;
+    int rc = bind_device(c); if (rc) return rc;
+    drain_profile(c);
+    auto it = c->profile.find(name);
+    if (launches) *launches = it == c->profile.end() ? 0 : it->second.launches;
+    if (total_ms) *total_ms = it == c->profile.end() ? 0.0 : it->second.total_ms;
+    if (reset && it != c->profile.end()) { it->second.launches = 0; it->second.total_ms = 0.0; }
+    return PTR_OK;
+}
+
+int ptr_profile_names(ptr_ctx* c, char* dst, size_t size) {
+    if (!c || !dst || size == 0) return PTR_E_INVALID;
+    std::string s;
+    for (auto& kv : c->profile) { if (!s.empty()) s += '\n'; s += kv.first; }
+    if (s.size() + 1 > size) return fail(c, PTR_E_RANGE, "ptr_profile_names: need %zu bytes", s.size() + 1);
+    memcpy(dst, s.c_str(), s.size() + 1);
+    return PTR_OK;
+}
+
+}  // extern "C"

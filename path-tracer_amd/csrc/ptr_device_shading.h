@@ -1,0 +1,352 @@
+// Device functions shared by the megakernel and the wavefront kernels: scene access, RNG, texture
+// fetch, BRDF sampling, camera rays and temporal accumulation.  Each block names the reference shader
+// lines whose behaviour it reproduces (shaders/compute.comp and shaders/include/*.h of the reference).
+#pragma once
+#pragma clang fp contract(off)
+
+#include "ptr_device_math.h"
+
+namespace ptr {
+
+// ---- records the kernels read ---------------------------------------------------------------------
+struct Material {  // 48 bytes, include/material.hpp:17-25 / compute.comp:21-29
+    float base_color[4];
+    uint32_t albedo_tex, albedo_sampler, mr_tex, mr_sampler;
+    float metalness, roughness;
+    float pad[2];
+};
+
+struct ThreadedNode {  // 32 bytes, include/bvh.hpp:17-22 / compute.comp:60-65
+    float min[3]; int32_t next_id;
+    float max[3]; int32_t primitive_id;
+};
+
+struct SceneMeta {  // 160 bytes, compute.comp:45-79 (note: `up` before `right`, as the SHADER declares them)
+    float position[4], forward[4], up[4], right[4], horizontal[4], vertical[4], first_pixel[4];
+    float lens_radius, cam_pad[3];
+    uint32_t max_bounce, min_bounce, width, height, sample_index, enable_dof, debug_bvh;
+    int32_t downscale_factor;
+};
+static_assert(sizeof(SceneMeta) == 160, "scene metadata is 160 bytes");
+
+struct ImageDesc {  // one entry of the bindless image table
+    void* data;
+    uint32_t width, height;
+    uint32_t format;   // PTR_FORMAT_*
+    uint32_t sampler;  // bindless sampler index
+};
+
+struct Capture { int32_t prim0; float t0; int32_t prim1; float t1; };
+
+// Everything one "compute" dispatch needs; built on the host from the 64-byte constant block.
+struct SceneView {
+    const SceneMeta* meta;
+    const ThreadedNode* nodes;
+    const uint32_t* indices;
+    const float* positions;
+    const float* normals;
+    const float* uvs;
+    const Material* materials;
+    const ImageDesc* images;   // bindless table
+    uint32_t image_count;
+    uint32_t output_index, accumulation_index;
+    Capture* capture;          // optional
+    unsigned long long* stats; // optional: [rays, nodes, triangles, shaded]
+    uint32_t part_rank, part_world, part_stripe_rows;
+};
+
+struct Ray { f3 origin, dir; float min_t, max_t; };
+struct Hit { float t, u, v; int32_t prim; };  // prim < 0: miss
+
+// ---- rand.h:1-12 -------------------------------------------------------------------------------------
+PTR_DEV uint32_t pcg_hash(uint32_t& seed) {
+    const uint32_t state = seed;
+    seed = state * (747796405u + 2891336453u);  // the shader's `seed *= a + b`: multiplier a+b, no increment
+    const uint32_t word = ((state >> ((state >> 28u) + 4u)) ^ state) * 277803737u;
+    return (word >> 22u) ^ word;
+}
+PTR_DEV float rand01(uint32_t& seed) { return (float)pcg_hash(seed) / 4294967296.0f; }
+
+// ---- color_utils.h:1-26 -----------------------------------------------------------------------------
+PTR_DEV float linear_to_srgb1(float c) {
+    c = clampf(c, 0.0f, 1.0f);
+    return mixf(pow_pos(c, 1.0f / 2.4f) * 1.055f - 0.055f, c * 12.92f, c < 0.0031308f ? 1.0f : 0.0f);
+}
+PTR_DEV float srgb_to_linear1(float c) {
+    c = clampf(c, 0.0f, 1.0f);
+    return mixf(pow_pos((c + 0.055f) / 1.055f, 2.4f), c / 12.92f, c < 0.04045f ? 1.0f : 0.0f);
+}
+PTR_DEV f3 linear_to_srgb(f3 c) { return mk3(linear_to_srgb1(c.x), linear_to_srgb1(c.y), linear_to_srgb1(c.z)); }
+PTR_DEV f3 srgb_to_linear(f3 c) { return mk3(srgb_to_linear1(c.x), srgb_to_linear1(c.y), srgb_to_linear1(c.z)); }
+PTR_DEV float luminance(f3 c) { return dot(c, mk3(0.2126f, 0.7152f, 0.0722f)); }
+
+// ---- math.h:12-45 ------------------------------------------------------------------------------------
+constexpr float kPi = 3.141592653589793f;
+constexpr float kTwoPi = kPi * 2.0f;
+
+PTR_DEV f3 sample_hemisphere(float r0, float r1) {
+    const float radius = sqrtf(r0);
+    const float theta = 2.0f * kPi * r1;
+    float s, c;
+    sincos_poly(theta, s, c);
+    return mk3(c * radius, s * radius, sqrtf(1.0f - r0));
+}
+PTR_DEV f2 disk_vec(float r0, float r1) {
+    const float z = r0 * 2.0f - 1.0f;
+    const float a = 2.0f * kPi * r1;
+    const float r = sqrtf(1.0f - z * z);
+    float s, c;
+    sincos_poly(a, s, c);
+    f2 o; o.x = c * r; o.y = s * r;
+    return o;
+}
+PTR_DEV f4 rotation_to_z_axis(f3 axis) {
+    f4 q;
+    if (axis.z < -0.99999f) { q.x = 1.0f; q.y = 0.0f; q.z = 0.0f; q.w = 0.0f; return q; }
+    const float x = axis.y, y = -axis.x, z = 0.0f, w = 1.0f + axis.z;
+    const float inv = rcp(sqrtf(x * x + y * y + z * z + w * w));
+    q.x = x * inv; q.y = y * inv; q.z = z * inv; q.w = w * inv;
+    return q;
+}
+PTR_DEV f4 invert_rotation(f4 q) { f4 r; r.x = -q.x; r.y = -q.y; r.z = -q.z; r.w = q.w; return r; }
+PTR_DEV f3 rotate_point(f4 q, f3 v) {
+    const f3 qa = mk3(q.x, q.y, q.z);
+    const f3 a = qa * (2.0f * dot(qa, v));
+    const f3 b = v * (q.w * q.w - dot(qa, qa));
+    const f3 c = cross(qa, v) * (2.0f * q.w);
+    return (a + b) + c;
+}
+
+// ---- brdf.h:13-99 --------------------------------------------------------------------------------------
+constexpr float kMinDielectricsF0 = 0.04f;
+
+// `seed` by value: the two draws made here do not advance the caller's generator (brdf.h:13).
+PTR_DEV f3 sample_ggx_vndf(f3 Ve, float ax, float ay, uint32_t seed) {
+    const f3 Vh = normalize(mk3(ax * Ve.x, ay * Ve.y, Ve.z));
+    const float lensq = Vh.x * Vh.x + Vh.y * Vh.y;
+    const f3 T1 = lensq > 0.0f ? mk3(-Vh.y, Vh.x, 0.0f) * rcp(sqrtf(lensq)) : mk3(1.0f, 0.0f, 0.0f);
+    const f3 T2 = cross(Vh, T1);
+    const float r = sqrtf(rand01(seed));
+    const float phi = kTwoPi * rand01(seed);
+    float sphi, cphi;
+    sincos_poly(phi, sphi, cphi);
+    const float t1 = r * cphi;
+    float t2 = r * sphi;
+    const float s = 0.5f * (1.0f + Vh.z);
+    t2 = mixf(sqrtf(1.0f - t1 * t1), t2, s);
+    const f3 Nh = ((T1 * t1) + (T2 * t2)) + (Vh * sqrtf(max_num(0.0f, 1.0f - t1 * t1 - t2 * t2)));
+    return normalize(mk3(ax * Nh.x, ay * Nh.y, max_num(0.0f, Nh.z)));
+}
+PTR_DEV float smith_g1_ggx(float alpha_squared, float NdotS_squared) {
+    return 2.0f / (sqrtf(((alpha_squared * (1.0f - NdotS_squared)) + NdotS_squared) / NdotS_squared) + 1.0f);
+}
+PTR_DEV f3 diffuse_reflectance(f3 base, float metalness) { return base * (1.0f - metalness); }
+PTR_DEV f3 fresnel_schlick(f3 f0, float f90, float NdotS) {
+    const float p = pow5(1.0f - NdotS);
+    return mk3(f0.x + (f90 - f0.x) * p, f0.y + (f90 - f0.y) * p, f0.z + (f90 - f0.z) * p);
+}
+PTR_DEV float shadowed_f90(f3 F0) { return min_num(1.0f, (1.0f / kMinDielectricsF0) * luminance(F0)); }
+PTR_DEV float brdf_probability(f3 color, float metalness, f3 view, f3 shading_normal) {
+    const float l = luminance(mk3(mixf(kMinDielectricsF0, color.x, metalness), mixf(kMinDielectricsF0, color.y, metalness),
+                                  mixf(kMinDielectricsF0, color.z, metalness)));
+    const f3 specular_F0 = mk3(l, l, l);
+    const float diffuse_refl = luminance(diffuse_reflectance(color, metalness));
+    const float fresnel =
+        clampf(luminance(fresnel_schlick(specular_F0, shadowed_f90(specular_F0), max_num(0.0f, dot(view, shading_normal)))), 0.0f, 1.0f);
+    const float specular = fresnel;
+    const float diffuse = diffuse_refl * (1.0f - fresnel);
+    const float p = specular / max_num(0.0001f, specular + diffuse);
+    return clampf(p, 0.1f, 0.9f);
+}
+
+// ---- texture(sampler2D, uv): compute.comp:142-153; LINEAR / REPEAT / lod 0 on RGBA8 UNORM ------------------
+PTR_DEV float fract_repeat(float x) {
+    float fr = x - floorf(x);
+    if (!(fr == fr)) fr = 0.0f;
+    return fr;
+}
+PTR_DEV f4 unpack_rgba8(uint32_t p) {
+    f4 r;
+    r.x = (float)(p & 0xffu) / 255.0f;
+    r.y = (float)((p >> 8) & 0xffu) / 255.0f;
+    r.z = (float)((p >> 16) & 0xffu) / 255.0f;
+    r.w = (float)(p >> 24) / 255.0f;
+    return r;
+}
+PTR_DEV f4 sample_bindless(const SceneView& sv, uint32_t texture_id, float u, float v) {
+    f4 white; white.x = white.y = white.z = white.w = 1.0f;
+    if (texture_id == 0u || texture_id >= sv.image_count) return white;
+    const ImageDesc d = sv.images[texture_id];
+    if (d.data == nullptr || d.width == 0u || d.height == 0u) return white;
+    const int32_t W = (int32_t)d.width, H = (int32_t)d.height;
+    const float x = fract_repeat(u) * (float)W - 0.5f;
+    const float y = fract_repeat(v) * (float)H - 0.5f;
+    const float fx = floorf(x), fy = floorf(y);
+    const float a = x - fx, b = y - fy;
+    int32_t i0 = (int32_t)fx, j0 = (int32_t)fy;
+    int32_t i1 = i0 + 1, j1 = j0 + 1;
+    // x in [-0.5, W - 0.5]: one conditional wrap replaces the modulo
+    i0 = i0 < 0 ? i0 + W : (i0 >= W ? i0 - W : i0);
+    i1 = i1 < 0 ? i1 + W : (i1 >= W ? i1 - W : i1);
+    j0 = j0 < 0 ? j0 + H : (j0 >= H ? j0 - H : j0);
+    j1 = j1 < 0 ? j1 + H : (j1 >= H ? j1 - H : j1);
+    const uint32_t* texels = (const uint32_t*)d.data;
+    const f4 c00 = unpack_rgba8(texels[(size_t)j0 * W + i0]);
+    const f4 c10 = unpack_rgba8(texels[(size_t)j0 * W + i1]);
+    const f4 c01 = unpack_rgba8(texels[(size_t)j1 * W + i0]);
+    const f4 c11 = unpack_rgba8(texels[(size_t)j1 * W + i1]);
+    f4 o;
+    o.x = (c00.x * (1.0f - a) + c10.x * a) * (1.0f - b) + (c01.x * (1.0f - a) + c11.x * a) * b;
+    o.y = (c00.y * (1.0f - a) + c10.y * a) * (1.0f - b) + (c01.y * (1.0f - a) + c11.y * a) * b;
+    o.z = (c00.z * (1.0f - a) + c10.z * a) * (1.0f - b) + (c01.z * (1.0f - a) + c11.z * a) * b;
+    o.w = (c00.w * (1.0f - a) + c10.w * a) * (1.0f - b) + (c01.w * (1.0f - a) + c11.w * a) * b;
+    return o;
+}
+
+// ---- ray.h:20-54 ----------------------------------------------------------------------------------------
+PTR_DEV void decode_triangle(const SceneView& sv, uint32_t tri, uint32_t& i0, uint32_t& i1, uint32_t& i2, uint32_t& mat) {
+    const uint32_t a = sv.indices[tri * 3u], b = sv.indices[tri * 3u + 1u], c = sv.indices[tri * 3u + 2u];
+    i0 = a & 0x00ffffffu; i1 = b & 0x00ffffffu; i2 = c & 0x00ffffffu;
+    mat = ((a & 0xff000000u) >> 8) | ((b & 0xff000000u) >> 16) | ((c & 0xff000000u) >> 24);
+}
+PTR_DEV f3 load3(const float* p, uint32_t i) { return mk3(p[i * 3u], p[i * 3u + 1u], p[i * 3u + 2u]); }
+
+// ---- compute.comp:247-262 -----------------------------------------------------------------------------
+PTR_DEV Ray generate_camera_ray(const SceneMeta& m, int32_t cx, int32_t cy, uint32_t seed /* by value */) {
+    const float sx = (float)(m.width - 1u), sy = (float)(m.height - 1u);
+    const float uvx = (float)cx / sx, uvy = 1.0f - (float)cy / sy;
+    const float d0 = rand01(seed);
+    const float d1 = rand01(seed);
+    const f2 rand_disk = disk_vec(d0, d1);
+    const float j0 = rand01(seed);
+    const float j1 = rand01(seed);
+    const float jx = uvx + j0 / sx, jy = uvy + j1 / sy;
+    float lx = 0.0f, ly = 0.0f;
+    if (m.enable_dof == 1u) { lx = rand_disk.x * m.lens_radius; ly = rand_disk.y * m.lens_radius; }
+    const f3 offset = (mk3(m.right[0], m.right[1], m.right[2]) * lx) + (mk3(m.up[0], m.up[1], m.up[2]) * ly);
+    const f3 pos = mk3(m.position[0], m.position[1], m.position[2]);
+    const f3 proj = (mk3(m.first_pixel[0], m.first_pixel[1], m.first_pixel[2]) +
+                     (mk3(m.horizontal[0], m.horizontal[1], m.horizontal[2]) * jx)) +
+                    (mk3(m.vertical[0], m.vertical[1], m.vertical[2]) * jy);
+    Ray r;
+    r.origin = pos + offset;
+    r.dir = (proj - pos) - offset;
+    r.min_t = 0.001f;
+    r.max_t = 1e15f;
+    return r;
+}
+
+PTR_DEV uint32_t pixel_seed(int32_t cx, int32_t cy, uint32_t sample_index) {  // compute.comp:270
+    return ((uint32_t)cx * 1973u + (uint32_t)cy * 9277u + sample_index * 26699u) | 1u;
+}
+
+// ---- one iteration of the bounce loop after the closest-hit query: compute.comp:130-241 -----------------
+// Inputs: the ray that was traced, its closest hit, the path state.  Returns true when the path goes on
+// (r holds the next ray), false when it ended with `result` (throughput on a miss, black otherwise).
+PTR_DEV bool shade_bounce(const SceneView& sv, uint32_t bounce, uint32_t min_bounce, const Hit& hit, Ray& r, f3& throughput,
+                          uint32_t& seed, f3& result) {
+    if (hit.prim < 0) { result = throughput * 1.0f; return false; }
+    result = mk3(0.0f, 0.0f, 0.0f);
+
+    const f3 v = -r.dir;
+    uint32_t i0, i1, i2, mat_id;
+    decode_triangle(sv, (uint32_t)hit.prim, i0, i1, i2, mat_id);
+    const f3 bary = mk3(1.0f - hit.u - hit.v, hit.u, hit.v);
+
+    // geometry normal and hit point as hit_triangle / hit_node produce them (ray.h:146,159,191)
+    const f3 p0 = load3(sv.positions, i0), p1 = load3(sv.positions, i1), p2 = load3(sv.positions, i2);
+    f3 geometry_normal = normalize(cross(p1 - p0, p2 - p0));
+    const f3 point = r.origin + r.dir * hit.t;
+
+    const f3 n0 = load3(sv.normals, i0), n1 = load3(sv.normals, i1), n2 = load3(sv.normals, i2);
+    f3 shading_normal = normalize(((n0 * bary.x) + (n1 * bary.y)) + (n2 * bary.z));
+    const float tu = (sv.uvs[i0 * 2u] * bary.x + sv.uvs[i1 * 2u] * bary.y) + sv.uvs[i2 * 2u] * bary.z;
+    const float tv = (sv.uvs[i0 * 2u + 1u] * bary.x + sv.uvs[i1 * 2u + 1u] * bary.y) + sv.uvs[i2 * 2u + 1u] * bary.z;
+
+    const Material mat = sv.materials[mat_id];
+    const f4 albedo = sample_bindless(sv, mat.albedo_tex, tu, tv);
+    const f3 diffuse_color = srgb_to_linear(mk3(albedo.x, albedo.y, albedo.z)) * mk3(mat.base_color[0], mat.base_color[1], mat.base_color[2]);
+    const f4 mr = sample_bindless(sv, mat.mr_tex, tu, tv);
+    const float metalness = mr.x * mat.metalness;  // R as metalness, G as roughness: the reference's choice
+    const float roughness = mr.y * mat.roughness;
+
+    if (dot(geometry_normal, v) < 0.f) geometry_normal = -geometry_normal;
+    if (dot(geometry_normal, shading_normal) < 0.0f) shading_normal = -shading_normal;
+
+    bool specular;
+    if (metalness == 1.f && roughness == 0.f) {
+        specular = true;
+    } else {
+        const float p = brdf_probability(diffuse_color, metalness, -r.dir, shading_normal);
+        if (rand01(seed) < p) { specular = true; throughput = throughput / p; }
+        else { specular = false; throughput = throughput / (1.0f - p); }
+    }
+
+    if (dot(shading_normal, v) <= 0.f) return false;
+
+    const f4 to_z = rotation_to_z_axis(shading_normal);
+    const f3 view_local = rotate_point(to_z, -r.dir);
+    f3 dir_local, weight;
+    if (!specular) {
+        const float r0 = rand01(seed);
+        const float r1 = rand01(seed);
+        dir_local = sample_hemisphere(r0, r1);
+        weight = diffuse_reflectance(diffuse_color, metalness);
+    } else {
+        const float alpha = roughness * roughness;
+        const float alpha_squared = alpha * alpha;
+        const f3 half_local = (alpha == 0.0f) ? mk3(0.0f, 0.0f, 1.0f) : sample_ggx_vndf(view_local, alpha, alpha, seed);
+        const f3 incident = -view_local;
+        const f3 light_local = incident - half_local * (2.0f * dot(half_local, incident));  // reflect(I, N)
+        const f3 specular_F0 = diffuse_reflectance(diffuse_color, metalness);                // as compute.comp:205 has it
+        const float HdotL = clampf(dot(half_local, light_local), 0.00001f, 1.0f);
+        const float NdotL = clampf(dot(mk3(0.0f, 0.0f, 1.0f), light_local), 0.00001f, 1.0f);
+        const f3 fr = fresnel_schlick(specular_F0, shadowed_f90(specular_F0), HdotL);
+        weight = fr * smith_g1_ggx(alpha_squared, NdotL * NdotL);
+        dir_local = light_local;
+    }
+
+    if (luminance(weight) == 0.0f) return false;
+
+    const f3 ray_dir = rotate_point(invert_rotation(to_z), dir_local);
+    if (dot(geometry_normal, ray_dir) <= 0.0f) return false;
+
+    throughput = throughput * weight;
+    r.origin = point; r.dir = ray_dir; r.min_t = 0.001f; r.max_t = 1e15f;
+
+    if (bounce > min_bounce) {  // Russian roulette
+        const float probability = min_num(0.95f, luminance(throughput));
+        if (probability < rand01(seed)) return false;
+        throughput = throughput / probability;
+    }
+    return true;
+}
+
+// ---- image access + temporal accumulation: compute.comp:280-288 ----------------------------------------
+PTR_DEV f4 image_load(const ImageDesc& im, int32_t x, int32_t y) {
+    f4 z; z.x = z.y = z.z = z.w = 0.0f;
+    if (im.data == nullptr || x < 0 || y < 0 || (uint32_t)x >= im.width || (uint32_t)y >= im.height) return z;
+    const float4 t = ((const float4*)im.data)[(size_t)y * im.width + (size_t)x];
+    f4 r; r.x = t.x; r.y = t.y; r.z = t.z; r.w = t.w;
+    return r;
+}
+PTR_DEV void image_store(const ImageDesc& im, int32_t x, int32_t y, f3 c) {
+    if (im.data == nullptr || x < 0 || y < 0 || (uint32_t)x >= im.width || (uint32_t)y >= im.height) return;
+    ((float4*)im.data)[(size_t)y * im.width + (size_t)x] = make_float4(c.x, c.y, c.z, 1.0f);
+}
+PTR_DEV void accumulate_pixel(const ImageDesc& acc, const ImageDesc& out, int32_t cx, int32_t cy, int32_t downscale,
+                              uint32_t sample_index, f3 sample) {
+    const float spp_scale = 1.0f / (float)sample_index;
+    const f4 a = image_load(acc, cx, cy);
+    const f3 prev = srgb_to_linear(mk3(a.x, a.y, a.z));
+    const f3 o = linear_to_srgb(mk3(mixf(prev.x, sample.x, spp_scale), mixf(prev.y, sample.y, spp_scale), mixf(prev.z, sample.z, spp_scale)));
+    for (int32_t i = 0; i < downscale; i++)
+        for (int32_t j = 0; j < downscale; j++) image_store(out, cx + i, cy + j, o);
+}
+
+// Does this context own image row `gy` of the dispatch under the stripe partition?
+PTR_DEV bool owns_row(const SceneView& sv, uint32_t gy) {
+    return sv.part_world <= 1u || ((gy / sv.part_stripe_rows) % sv.part_world) == sv.part_rank;
+}
+
+}  // namespace ptr

@@ -1,0 +1,53 @@
+// Host-side launch interface of the HIP kernels (implemented in ptr_kernels_mega.hip and
+// ptr_kernels_wavefront.hip).  Everything is enqueued on the given stream; nothing synchronises.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "ptr_device_shading.h"
+
+namespace ptr {
+
+// Flattened BVH (the blob bvh::flatten() emits), as device pointers.
+struct FlatView {
+    const float4* nodes;      // 4 x float4 per 64-byte node
+    const float4* triangles;  // 4 x float4 per 64-byte triangle record
+    int32_t root;
+    uint32_t max_depth;
+};
+
+// Scratch of the wavefront pipeline, owned by the context, sized for `capacity` paths.
+struct WavefrontScratch {
+    // ray + path state, structure-of-arrays, two generations (read bounce b, write bounce b+1)
+    float* ray[2][6];       // origin xyz, direction xyz
+    float* throughput[2][3];
+    uint32_t* seed[2];
+    uint32_t* pixel[2];     // gy * width + gx of the dispatch
+    float4* hits;           // t, u, v, prim (bits)
+    float4* samples;        // per pixel: the sample's colour (w unused)
+    uint32_t* counters;     // [0..15]: live paths entering bounce b; [16..31]: fetch cursors of the extend kernel
+    int32_t* stack_spill;   // traversal stack overflow area of the persistent extend grid
+    uint32_t capacity;
+    uint32_t extend_blocks; // persistent grid size
+};
+
+constexpr uint32_t kMaxBounceSlots = 16;   // counters per array; deeper paths reuse the slots cyclically
+constexpr uint32_t kExtendThreads = 256;
+constexpr uint32_t kStackLds = 24;         // per-lane traversal stack entries kept in LDS
+constexpr uint32_t kStackSpill = 40;       // further entries in global memory (64 total >= FLAT_BVH_MAX_DEPTH)
+
+// compute.comp as one kernel over the threaded node array (one wave = one 8x8 workgroup).
+hipError_t launch_megakernel(hipStream_t s, const SceneView& sv, uint32_t groups_x, uint32_t groups_y, bool stats);
+// tonemapping.comp
+hipError_t launch_tonemap(hipStream_t s, const SceneMeta* meta, const ImageDesc* images, uint32_t image_count,
+                          uint32_t output_index, uint32_t accumulation_index, uint32_t groups_x, uint32_t groups_y);
+
+// Wavefront stages.  domain_w/h = pixels of the dispatch that exist (min(groups*8, width/height)).
+hipError_t launch_wf_generate(hipStream_t s, const SceneView& sv, const WavefrontScratch& w, uint32_t domain_w, uint32_t domain_h);
+hipError_t launch_wf_extend(hipStream_t s, const FlatView& fv, const WavefrontScratch& w, uint32_t bounce, unsigned long long* stats);
+hipError_t launch_wf_shade(hipStream_t s, const SceneView& sv, const WavefrontScratch& w, uint32_t bounce, uint32_t max_bounce,
+                           uint32_t min_bounce, uint32_t domain_w, uint32_t domain_h);
+hipError_t launch_wf_accumulate(hipStream_t s, const SceneView& sv, const WavefrontScratch& w, uint32_t domain_w, uint32_t domain_h);
+
+}  // namespace ptr

@@ -1,0 +1,171 @@
+// "compute" as a single kernel over the reference's threaded node array, and "tonemapping".
+//
+// This is the drop-in path: it consumes exactly the seven buffers + two images the reference's
+// constant block names (compute.comp:109-120) and walks the 32-byte skip-link nodes the reference's
+// builder emits, so every pixel follows the reference's traversal order, tie-breaking and RNG stream.
+// One wave64 = one 8x8 workgroup of the reference's dispatch (compute.comp:14), one lane = one pixel.
+#pragma clang fp contract(off)
+
+#include "ptr_kernels.h"
+
+namespace ptr {
+
+// ray.h:66-78 with the reciprocal direction hoisted (it is a pure function of the ray).
+PTR_DEV bool hit_aabb(const float4 lo, const float4 hi, const f3 origin, const f3 inv_dir, float min_t, float max_t) {
+    const f3 fv = (mk3(hi.x, hi.y, hi.z) - origin) * inv_dir;
+    const f3 nv = (mk3(lo.x, lo.y, lo.z) - origin) * inv_dir;
+    const float t1 = min_num(min_num(max_num(fv.x, nv.x), min_num(max_num(fv.y, nv.y), max_num(fv.z, nv.z))), max_t);
+    const float t0 = max_num(max_num(max_num(min_num(fv.x, nv.x), max_num(min_num(fv.y, nv.y), min_num(fv.z, nv.z))), min_t), 0.0f);
+    return t1 >= t0;
+}
+
+// ray.h:137-163.  Accepts exactly what the shader accepts (a NaN passes every rejection test).
+PTR_DEV bool hit_triangle(const SceneView& sv, uint32_t id, const Ray& r, float max_t, float& t_out, float& u_out, float& v_out) {
+    uint32_t i0, i1, i2, mat;
+    decode_triangle(sv, id, i0, i1, i2, mat);
+    const f3 p0 = load3(sv.positions, i0);
+    const f3 e1 = load3(sv.positions, i1) - p0;
+    const f3 e2 = load3(sv.positions, i2) - p0;
+    const f3 ov = r.origin - p0;
+    const f3 n = cross(e1, e2);
+    const f3 q = cross(ov, r.dir);
+    const float d = rcp(dot(r.dir, n));
+    const float u = d * dot(-q, e2);
+    const float v = d * dot(q, e1);
+    const float t = d * dot(-n, ov);
+    if (u < 0.0f || u > 1.0f || v < 0.0f || u + v > 1.0f || t < r.min_t || t > max_t) return false;
+    t_out = t; u_out = u; v_out = v;
+    return true;
+}
+
+// ray.h:165-193: stackless walk, left child first, leaves tested without a box test, a hit shrinks max_t,
+// `t > max_t` rejects so an equal t replaces the earlier hit.
+template <bool STATS>
+PTR_DEV Hit hit_node(const SceneView& sv, const Ray& r, unsigned long long& n_nodes, unsigned long long& n_tris) {
+    Hit best; best.prim = -1; best.t = 0.0f; best.u = 0.0f; best.v = 0.0f;
+    float max_t = r.max_t;
+    const f3 inv_dir = mk3(rcp(r.dir.x), rcp(r.dir.y), rcp(r.dir.z));
+    const float4* nodes = (const float4*)sv.nodes;
+    int32_t id = 0;
+    while (id != -1) {
+        const float4 lo = nodes[2 * id];      // min.xyz, next_id
+        const float4 hi = nodes[2 * id + 1];  // max.xyz, primitive_id
+        const int32_t next_id = __float_as_int(lo.w);
+        const int32_t prim = __float_as_int(hi.w);
+        if (STATS) n_nodes++;
+        if (prim != -1) {
+            float t, u, v;
+            if (STATS) n_tris++;
+            if (hit_triangle(sv, (uint32_t)prim, r, max_t, t, u, v)) {
+                best.prim = prim; best.t = t; best.u = u; best.v = v;
+                max_t = t;
+            }
+            id = next_id;
+        } else if (hit_aabb(lo, hi, r.origin, inv_dir, r.min_t, max_t)) {
+            id++;
+        } else {
+            id = next_id;
+        }
+    }
+    return best;
+}
+
+// ray.h:80-103
+PTR_DEV uint32_t hit_aabbs(const SceneView& sv, const Ray& r) {
+    const f3 inv_dir = mk3(rcp(r.dir.x), rcp(r.dir.y), rcp(r.dir.z));
+    const float4* nodes = (const float4*)sv.nodes;
+    uint32_t count = 0;
+    int32_t id = 0;
+    while (id != -1) {
+        const float4 lo = nodes[2 * id];
+        const float4 hi = nodes[2 * id + 1];
+        if (__float_as_int(hi.w) != -1) id = __float_as_int(lo.w);
+        else if (hit_aabb(lo, hi, r.origin, inv_dir, r.min_t, r.max_t)) { count++; id++; }
+        else id = __float_as_int(lo.w);
+    }
+    return count;
+}
+
+// compute.comp:264-289
+template <bool STATS>
+__global__ __launch_bounds__(64) void ptr_compute_megakernel(SceneView sv, uint32_t groups_x) {
+    const SceneMeta& m = *sv.meta;
+    const uint32_t group = blockIdx.x;
+    const uint32_t lane = threadIdx.x;
+    const uint32_t gx = (group % groups_x) * 8u + (lane & 7u);
+    const uint32_t gy = (group / groups_x) * 8u + (lane >> 3);
+    const bool valid = gx < m.width && gy < m.height && owns_row(sv, gy);
+
+    unsigned long long n_rays = 0, n_nodes = 0, n_tris = 0, n_shaded = 0;
+    if (valid) {
+        const int32_t cx = (int32_t)gx * m.downscale_factor, cy = (int32_t)gy * m.downscale_factor;
+        uint32_t seed = pixel_seed(cx, cy, m.sample_index);
+        Ray r = generate_camera_ray(m, cx, cy, seed);
+
+        Capture cap; cap.prim0 = -1; cap.t0 = 0.0f; cap.prim1 = -1; cap.t1 = 0.0f;
+        f3 out_color = mk3(0.0f, 0.0f, 0.0f);
+        if (m.debug_bvh == 1u) {
+            const float n = (float)hit_aabbs(sv, r);
+            out_color = mk3(n * 0.001f, n * 0.0f, n * 0.0f);
+        } else {
+            f3 throughput = mk3(1.0f, 1.0f, 1.0f);
+            const uint32_t max_bounce = m.max_bounce, min_bounce = m.min_bounce;
+            for (uint32_t bounce = 0; bounce < max_bounce; bounce++) {
+                const Hit h = hit_node<STATS>(sv, r, n_nodes, n_tris);
+                if (STATS) { n_rays++; if (h.prim >= 0) n_shaded++; }
+                if (bounce == 0u) { cap.prim0 = h.prim; cap.t0 = h.prim >= 0 ? h.t : 0.0f; }
+                if (bounce == 1u) { cap.prim1 = h.prim; cap.t1 = h.prim >= 0 ? h.t : 0.0f; }
+                if (!shade_bounce(sv, bounce, min_bounce, h, r, throughput, seed, out_color)) break;
+            }
+        }
+        if (sv.capture) sv.capture[(size_t)gy * m.width + gx] = cap;
+        accumulate_pixel(sv.images[sv.accumulation_index], sv.images[sv.output_index], cx, cy, m.downscale_factor,
+                         m.sample_index, out_color);
+    }
+
+    if (STATS && sv.stats) {  // every lane of the wave is here: reduce, then one atomic per counter
+        for (int off = 32; off > 0; off >>= 1) {
+            n_rays += __shfl_down(n_rays, off);
+            n_nodes += __shfl_down(n_nodes, off);
+            n_tris += __shfl_down(n_tris, off);
+            n_shaded += __shfl_down(n_shaded, off);
+        }
+        if (lane == 0u) {
+            atomicAdd(&sv.stats[0], n_rays); atomicAdd(&sv.stats[1], n_nodes);
+            atomicAdd(&sv.stats[2], n_tris); atomicAdd(&sv.stats[3], n_shaded);
+        }
+    }
+}
+
+// tonemapping.comp:19-30.  The shader has no bounds guard; image_load/image_store apply the image rules
+// (outside reads give 0, outside writes are dropped).
+__global__ __launch_bounds__(64) void ptr_tonemapping(const SceneMeta* meta, const ImageDesc* images, uint32_t image_count,
+                                                      uint32_t output_index, uint32_t accumulation_index, uint32_t groups_x) {
+    const int32_t ds = meta->downscale_factor;
+    const uint32_t group = blockIdx.x, lane = threadIdx.x;
+    const int32_t cx = (int32_t)((group % groups_x) * 8u + (lane & 7u)) * ds;
+    const int32_t cy = (int32_t)((group / groups_x) * 8u + (lane >> 3)) * ds;
+    if (output_index >= image_count || accumulation_index >= image_count) return;
+    const f4 a = image_load(images[accumulation_index], cx, cy);
+    const f3 o = mk3(sqrtf(a.x), sqrtf(a.y), sqrtf(a.z));
+    for (int32_t i = 0; i < ds; i++)
+        for (int32_t j = 0; j < ds; j++) image_store(images[output_index], cx + i, cy + j, o);
+}
+
+hipError_t launch_megakernel(hipStream_t s, const SceneView& sv, uint32_t groups_x, uint32_t groups_y, bool stats) {
+    const uint32_t blocks = groups_x * groups_y;
+    if (blocks == 0) return hipSuccess;
+    if (stats) hipLaunchKernelGGL(ptr_compute_megakernel<true>, dim3(blocks), dim3(64), 0, s, sv, groups_x);
+    else hipLaunchKernelGGL(ptr_compute_megakernel<false>, dim3(blocks), dim3(64), 0, s, sv, groups_x);
+    return hipGetLastError();
+}
+
+hipError_t launch_tonemap(hipStream_t s, const SceneMeta* meta, const ImageDesc* images, uint32_t image_count,
+                          uint32_t output_index, uint32_t accumulation_index, uint32_t groups_x, uint32_t groups_y) {
+    const uint32_t blocks = groups_x * groups_y;
+    if (blocks == 0) return hipSuccess;
+    hipLaunchKernelGGL(ptr_tonemapping, dim3(blocks), dim3(64), 0, s, meta, images, image_count, output_index, accumulation_index, groups_x);
+    return hipGetLastError();
+}
+
+}  // namespace ptr
