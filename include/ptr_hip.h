@@ -92,6 +92,12 @@ int ptr_dispatch(ptr_ctx* ctx, const char* kernel, const uint8_t constants[64], 
  *      the 8-row-aligned stripes s with s % world == rank, stripe = stripe_rows image rows.
  *      world = 1 restores the whole frame. ---- */
 int ptr_set_partition(ptr_ctx* ctx, uint32_t rank, uint32_t world, uint32_t stripe_rows);
+/* ---- multi-GPU sample partition (no counterpart in the reference): frame `sample_index` of this context
+ *      draws the global sample (sample_index - 1) * world + rank + 1 over the whole frame and keeps the running
+ *      mean of its own samples.  The per-GPU means are combined with the two extra dispatch names
+ *      "linearize" (output = sRGB-decoded accumulation image, alpha 1) -> sum over GPUs (RCCL all-reduce) ->
+ *      "resolve" (output = sRGB-encoded accumulation.rgb / accumulation.a).  world = 1 turns it off. ---- */
+int ptr_set_sample_partition(ptr_ctx* ctx, uint32_t rank, uint32_t world);
 
 /* ---- instrumentation (no counterpart in the reference) ---- */
 /* Per-pixel capture of the first two closest hits of the next "compute" dispatches: 16 bytes per pixel

@@ -55,6 +55,7 @@ struct ptr_ctx {
     std::vector<SamplerRec> samplers{ 1 };
     ptr::ImageDesc* d_images = nullptr;     // device copy of the bindless image table
     uint32_t part_rank = 0, part_world = 1, part_stripe = 8;
+    uint32_t sample_rank = 0, sample_world = 1;
     ptr_handle capture = 0;
     bool stats_on = false;
     unsigned long long* d_stats = nullptr;  // 8 counters
@@ -65,6 +66,12 @@ struct ptr_ctx {
     ptr::WavefrontScratch scratch{};
     void* scratch_block = nullptr;
     int cu_count = 256;
+    // small host->device writes (the per-frame 160-byte metadata) go through a ring of pinned slots so that
+    // Buffer::write returns without draining the stream
+    static constexpr int kStageSlots = 32;
+    uint8_t* stage = nullptr;              // kStageSlots x kShadowLimit bytes, pinned
+    hipEvent_t stage_done[kStageSlots] = {};
+    int stage_next = 0;
 };
 
 namespace {
@@ -249,6 +256,7 @@ int dispatch_compute(ptr_ctx* c, const uint8_t constants[64], uint32_t gx, uint3
     sv.output_index = k.output_index;
     sv.accumulation_index = k.accumulation_index;
     sv.part_rank = c->part_rank; sv.part_world = c->part_world; sv.part_stripe_rows = c->part_stripe;
+    sv.sample_rank = c->sample_rank; sv.sample_world = c->sample_world;
     sv.capture = nullptr;
     if (c->capture) {
         BufferRec* cb = find_buffer(c, c->capture);
@@ -334,6 +342,9 @@ int ptr_ctx_create(int device, ptr_ctx** out) {
     c->stream = c->own_stream;
     if ((e = hipMalloc((void**)&c->d_images, kMaxImages * sizeof(ptr::ImageDesc))) != hipSuccess) return bail("hipMalloc(image table)", e);
     if ((e = hipMemset(c->d_images, 0, kMaxImages * sizeof(ptr::ImageDesc))) != hipSuccess) return bail("hipMemset(image table)", e);
+    if ((e = hipHostMalloc((void**)&c->stage, (size_t)ptr_ctx::kStageSlots * kShadowLimit, hipHostMallocDefault)) != hipSuccess) return bail("hipHostMalloc(staging ring)", e);
+    for (int i = 0; i < ptr_ctx::kStageSlots; i++)
+        if ((e = hipEventCreateWithFlags(&c->stage_done[i], hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate(staging ring)", e);
     if ((e = hipMalloc((void**)&c->d_stats, 8 * sizeof(unsigned long long))) != hipSuccess) return bail("hipMalloc(stats)", e);
     if ((e = hipMemset(c->d_stats, 0, 8 * sizeof(unsigned long long))) != hipSuccess) return bail("hipMemset(stats)", e);
     *out = c;
@@ -351,6 +362,8 @@ int ptr_ctx_destroy(ptr_ctx* c) {
     if (c->scratch_block) (void)hipFree(c->scratch_block);
     if (c->d_images) (void)hipFree(c->d_images);
     if (c->d_stats) (void)hipFree(c->d_stats);
+    for (auto e : c->stage_done) if (e) (void)hipEventDestroy(e);
+    if (c->stage) (void)hipHostFree(c->stage);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
     return PTR_OK;
@@ -410,6 +423,16 @@ int ptr_buffer_write(ptr_ctx* c, ptr_handle h, const void* data, size_t offset, 
     int rc = bind_device(c); if (rc) return rc;
     if (!b->shadow.empty()) memcpy(b->shadow.data() + offset, data, size);
     b->flat_view_valid = false;
+    if (size <= kShadowLimit && c->stage) {
+        const int slot = c->stage_next;
+        c->stage_next = (slot + 1) % ptr_ctx::kStageSlots;
+        PTR_HIP_CHECK(c, hipEventSynchronize(c->stage_done[slot]));  // the copy that last used this slot has finished
+        uint8_t* pinned = c->stage + (size_t)slot * kShadowLimit;
+        memcpy(pinned, data, size);
+        PTR_HIP_CHECK(c, hipMemcpyAsync((uint8_t*)b->ptr + offset, pinned, size, hipMemcpyHostToDevice, c->stream));
+        PTR_HIP_CHECK(c, hipEventRecord(c->stage_done[slot], c->stream));
+        return PTR_OK;
+    }
     // Buffer::write is a memcpy into mapped memory in the reference: the caller may reuse `data` at once.
     PTR_HIP_CHECK(c, hipMemcpyAsync((uint8_t*)b->ptr + offset, data, size, hipMemcpyHostToDevice, c->stream));
     PTR_HIP_CHECK(c, hipStreamSynchronize(c->stream));
@@ -565,7 +588,18 @@ int ptr_dispatch(ptr_ctx* c, const char* kernel, const uint8_t constants[64], ui
                                              k.output_index, k.accumulation_index, gx, gy));
         return PTR_OK;
     }
-    return fail(c, PTR_E_INVALID, "ptr_dispatch: unknown kernel '%s' (compute, compute.megakernel, compute.wavefront, tonemapping)", kernel);
+    if (!strcmp(kernel, "linearize") || !strcmp(kernel, "resolve")) {
+        const ParsedConstants k = parse_constants(constants);
+        if ((rc = check_storage_image(c, k.output_index, "output"))) return rc;
+        if ((rc = check_storage_image(c, k.accumulation_index, "accumulation"))) return rc;
+        const ImageRec& a = c->images[k.accumulation_index];
+        const ImageRec& o = c->images[k.output_index];
+        if (a.w != o.w || a.h != o.h) return fail(c, PTR_E_STATE, "%s: output and accumulation images differ in size", kernel);
+        ScopedProfile prof(c, kernel[0] == 'l' ? "linearize" : "resolve");
+        PTR_HIP_CHECK(c, ptr::launch_linearize_resolve(c->stream, c->d_images, k.output_index, k.accumulation_index, a.w * a.h, kernel[0] == 'r'));
+        return PTR_OK;
+    }
+    return fail(c, PTR_E_INVALID, "ptr_dispatch: unknown kernel '%s' (compute, compute.megakernel, compute.wavefront, tonemapping, linearize, resolve)", kernel);
 }
 
 int ptr_set_partition(ptr_ctx* c, uint32_t rank, uint32_t world, uint32_t stripe_rows) {
@@ -573,6 +607,13 @@ int ptr_set_partition(ptr_ctx* c, uint32_t rank, uint32_t world, uint32_t stripe
     if (world == 0 || rank >= world) return fail(c, PTR_E_INVALID, "ptr_set_partition: rank %u / world %u", rank, world);
     if (stripe_rows == 0 || (stripe_rows & 7u)) return fail(c, PTR_E_INVALID, "ptr_set_partition: stripe_rows must be a positive multiple of 8");
     c->part_rank = rank; c->part_world = world; c->part_stripe = stripe_rows;
+    return PTR_OK;
+}
+
+int ptr_set_sample_partition(ptr_ctx* c, uint32_t rank, uint32_t world) {
+    if (!c) return PTR_E_INVALID;
+    if (world == 0 || rank >= world) return fail(c, PTR_E_INVALID, "ptr_set_sample_partition: rank %u / world %u", rank, world);
+    c->sample_rank = rank; c->sample_world = world;
     return PTR_OK;
 }
 

@@ -52,7 +52,8 @@ struct SceneView {
     uint32_t output_index, accumulation_index;
     Capture* capture;          // optional
     unsigned long long* stats; // optional: [rays, nodes, triangles, shaded]
-    uint32_t part_rank, part_world, part_stripe_rows;
+    uint32_t part_rank, part_world, part_stripe_rows;  // tile partition: stripes of rows
+    uint32_t sample_rank, sample_world;                 // sample partition: which global samples this GPU draws
 };
 
 struct Ray { f3 origin, dir; float min_t, max_t; };
@@ -342,6 +343,13 @@ PTR_DEV void accumulate_pixel(const ImageDesc& acc, const ImageDesc& out, int32_
     const f3 o = linear_to_srgb(mk3(mixf(prev.x, sample.x, spp_scale), mixf(prev.y, sample.y, spp_scale), mixf(prev.z, sample.z, spp_scale)));
     for (int32_t i = 0; i < downscale; i++)
         for (int32_t j = 0; j < downscale; j++) image_store(out, cx + i, cy + j, o);
+}
+
+// Sample partition: frame `sample_index` of GPU `sample_rank` draws the global sample
+// (sample_index - 1) * world + rank + 1, so the GPUs of a node draw disjoint sample sets; the temporal
+// weight stays 1 / sample_index (each GPU keeps the running mean of its own samples).
+PTR_DEV uint32_t seed_sample_index(const SceneView& sv, uint32_t sample_index) {
+    return sv.sample_world <= 1u ? sample_index : (sample_index - 1u) * sv.sample_world + sv.sample_rank + 1u;
 }
 
 // Does this context own image row `gy` of the dispatch under the stripe partition?

@@ -43,6 +43,10 @@ hipError_t launch_megakernel(hipStream_t s, const SceneView& sv, uint32_t groups
 hipError_t launch_tonemap(hipStream_t s, const SceneMeta* meta, const ImageDesc* images, uint32_t image_count,
                           uint32_t output_index, uint32_t accumulation_index, uint32_t groups_x, uint32_t groups_y);
 
+// Sample-partition exchange helpers over two same-sized RGBA32F images.
+hipError_t launch_linearize_resolve(hipStream_t s, const ImageDesc* images, uint32_t output_index, uint32_t accumulation_index,
+                                    uint32_t pixels, bool resolve);
+
 // Wavefront stages.  domain_w/h = pixels of the dispatch that exist (min(groups*8, width/height)).
 hipError_t launch_wf_generate(hipStream_t s, const SceneView& sv, const WavefrontScratch& w, uint32_t domain_w, uint32_t domain_h);
 hipError_t launch_wf_extend(hipStream_t s, const FlatView& fv, const WavefrontScratch& w, uint32_t bounce, unsigned long long* stats);

@@ -99,7 +99,7 @@ __global__ __launch_bounds__(64) void ptr_compute_megakernel(SceneView sv, uint3
     unsigned long long n_rays = 0, n_nodes = 0, n_tris = 0, n_shaded = 0;
     if (valid) {
         const int32_t cx = (int32_t)gx * m.downscale_factor, cy = (int32_t)gy * m.downscale_factor;
-        uint32_t seed = pixel_seed(cx, cy, m.sample_index);
+        uint32_t seed = pixel_seed(cx, cy, seed_sample_index(sv, m.sample_index));
         Ray r = generate_camera_ray(m, cx, cy, seed);
 
         Capture cap; cap.prim0 = -1; cap.t0 = 0.0f; cap.prim1 = -1; cap.t1 = 0.0f;
@@ -150,6 +150,29 @@ __global__ __launch_bounds__(64) void ptr_tonemapping(const SceneMeta* meta, con
     const f3 o = mk3(sqrtf(a.x), sqrtf(a.y), sqrtf(a.z));
     for (int32_t i = 0; i < ds; i++)
         for (int32_t j = 0; j < ds; j++) image_store(images[output_index], cx + i, cy + j, o);
+}
+
+// Sample-partition exchange helpers (no counterpart in the single-GPU reference).
+//   linearize: out = (srgb_to_linear(acc.rgb), 1)   -- undo the accumulate kernel's sRGB encoding so that images add
+//   resolve:   out = (linear_to_srgb(acc.rgb / acc.w), 1) -- after summing `acc.w` linearized images
+__global__ __launch_bounds__(256) void ptr_linearize_resolve(const ImageDesc* images, uint32_t output_index, uint32_t accumulation_index,
+                                                            uint32_t resolve) {
+    const ImageDesc src = images[accumulation_index], dst = images[output_index];
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= src.width * src.height || src.width != dst.width || src.height != dst.height) return;
+    const float4 a = ((const float4*)src.data)[i];
+    f3 o;
+    if (resolve) o = linear_to_srgb(mk3(a.x / a.w, a.y / a.w, a.z / a.w));
+    else o = srgb_to_linear(mk3(a.x, a.y, a.z));
+    ((float4*)dst.data)[i] = make_float4(o.x, o.y, o.z, 1.0f);
+}
+
+hipError_t launch_linearize_resolve(hipStream_t s, const ImageDesc* images, uint32_t output_index, uint32_t accumulation_index,
+                                    uint32_t pixels, bool resolve) {
+    if (pixels == 0) return hipSuccess;
+    hipLaunchKernelGGL(ptr_linearize_resolve, dim3((pixels + 255u) / 256u), dim3(256), 0, s, images, output_index, accumulation_index,
+                       resolve ? 1u : 0u);
+    return hipGetLastError();
 }
 
 hipError_t launch_megakernel(hipStream_t s, const SceneView& sv, uint32_t groups_x, uint32_t groups_y, bool stats) {

@@ -44,7 +44,7 @@ __global__ __launch_bounds__(256) void ptr_wf_generate(SceneView sv, WavefrontSc
     uint32_t seed = 0u;
     if (valid) {
         const int32_t cx = (int32_t)gx * m.downscale_factor, cy = (int32_t)gy * m.downscale_factor;
-        seed = pixel_seed(cx, cy, m.sample_index);
+        seed = pixel_seed(cx, cy, seed_sample_index(sv, m.sample_index));
         r = generate_camera_ray(m, cx, cy, seed);  // seed by value: the bounce loop restarts from it
         if (sv.capture) { Capture c; c.prim0 = -1; c.t0 = 0.0f; c.prim1 = -1; c.t1 = 0.0f; sv.capture[(size_t)gy * m.width + gx] = c; }
     }

@@ -1,0 +1,59 @@
+"""Multi-GPU exchange steps of the render path, one process per GPU over torch.distributed
+(backend "nccl" = RCCL over xGMI on the GPU node, "gloo" in the CPU tests).
+
+Two partitions of the work (the scene is replicated on every GPU):
+
+  tile partition    rank r renders the 8-row-aligned stripes s with s % world == r of every frame
+                    (ptr_set_partition); pixels never interact, so the merged image is bit-identical to the
+                    single-GPU frame.  Exchange: ONE all-gather of the owned stripes (frame / world bytes per rank).
+  sample partition  rank r renders whole frames for the global samples r+1, r+1+world, ... (ptr_set_sample_partition)
+                    and keeps the running mean of its own samples.  Exchange: all-reduce(sum) of the linearized
+                    means, then resolve.  Not bit-equal to sequential accumulation (the per-frame clamp and sRGB
+                    round trip of the accumulate step are nonlinear): checked by tolerance only.
+"""
+import torch
+import torch.distributed as dist
+
+
+def owned_stripes(rank, world, stripe_rows, height):
+    """Indices of the stripes (of `stripe_rows` image rows) that `rank` renders."""
+    n_stripes = (height + stripe_rows - 1) // stripe_rows
+    return list(range(rank, n_stripes, world))
+
+
+def owned_row_mask(rank, world, stripe_rows, height):
+    rows = torch.arange(height)
+    return ((rows // stripe_rows) % world) == rank
+
+
+def _padded_view(image, stripe_rows, world):
+    """image: (H, W, 4).  Returns (padded (S, stripe_rows, W, 4) tensor, S) with S a multiple of world."""
+    H, W, C = image.shape
+    n_stripes = (H + stripe_rows - 1) // stripe_rows
+    n_padded = ((n_stripes + world - 1) // world) * world
+    pad_rows = n_padded * stripe_rows - H
+    if pad_rows:
+        image = torch.cat([image, image.new_zeros((pad_rows, W, C))], dim=0)
+    return image.view(n_padded, stripe_rows, W, C), n_padded
+
+
+def gather_tiles(image, rank, world, stripe_rows, group=None):
+    """All-gathers the stripes each rank owns into the full frame.  `image` is this rank's (H, W, 4) frame whose
+    owned rows are valid; returns the merged (H, W, 4) frame (a new tensor), identical on every rank."""
+    if world == 1:
+        return image.clone()
+    H = image.shape[0]
+    stripes, n_padded = _padded_view(image, stripe_rows, world)
+    mine = stripes[rank::world].contiguous()                      # (n_padded / world, stripe_rows, W, 4)
+    gathered = torch.empty((world,) + tuple(mine.shape), dtype=image.dtype, device=image.device)
+    dist.all_gather_into_tensor(gathered.view(-1), mine.view(-1), group=group)
+    # gathered[r, j] is stripe j * world + r
+    merged = gathered.permute(1, 0, 2, 3, 4).reshape(n_padded * stripe_rows, image.shape[1], image.shape[2])
+    return merged[:H].contiguous()
+
+
+def allreduce_linear(image_linear, group=None):
+    """Sums the linearized per-GPU means in place (alpha carries the number of contributions)."""
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(image_linear, op=dist.ReduceOp.SUM, group=group)
+    return image_linear

@@ -61,6 +61,7 @@ def lib():
         "ptr_bvh_bind_flat": [vp, u32, u32],
         "ptr_dispatch": [vp, C.c_char_p, vp, u32, u32, u32],
         "ptr_set_partition": [vp, u32, u32, u32],
+        "ptr_set_sample_partition": [vp, u32, u32],
         "ptr_set_capture": [vp, u32],
         "ptr_stats_enable": [vp, C.c_int],
         "ptr_stats_read": [vp, P(u64), C.c_int],
@@ -82,7 +83,7 @@ ABI_SYMBOLS = ["ptr_ctx_create", "ptr_ctx_destroy", "ptr_ctx_set_stream", "ptr_l
                "ptr_buffer_destroy", "ptr_buffer_write", "ptr_buffer_read", "ptr_buffer_address", "ptr_sampler_create",
                "ptr_image_create", "ptr_image_wrap", "ptr_image_destroy", "ptr_image_upload", "ptr_image_read",
                "ptr_image_index", "ptr_sampler_index", "ptr_image_address", "ptr_bvh_bind_flat", "ptr_dispatch",
-               "ptr_set_partition", "ptr_set_capture", "ptr_stats_enable", "ptr_stats_read", "ptr_profile_enable",
+               "ptr_set_partition", "ptr_set_sample_partition", "ptr_set_capture", "ptr_stats_enable", "ptr_stats_read", "ptr_profile_enable",
                "ptr_profile_read", "ptr_profile_names"]
 
 
@@ -138,6 +139,9 @@ class Context:
     # ---- instrumentation ----
     def set_partition(self, rank, world, stripe_rows=8):
         self._check(self._L.ptr_set_partition(self.handle, rank, world, stripe_rows))
+
+    def set_sample_partition(self, rank, world):
+        self._check(self._L.ptr_set_sample_partition(self.handle, rank, world))
 
     def set_capture(self, buffer):
         self._check(self._L.ptr_set_capture(self.handle, buffer.handle if buffer is not None else 0))
@@ -255,7 +259,7 @@ class ComputeRenderpass:
         self.output_texture = None
 
     def set_pipeline(self, shader_name):
-        if shader_name not in ("compute", "compute.megakernel", "compute.wavefront", "tonemapping"):
+        if shader_name not in ("compute", "compute.megakernel", "compute.wavefront", "tonemapping", "linearize", "resolve"):
             raise HipError(f"set_pipeline: unknown shader '{shader_name}'")
         self.pipeline = shader_name
 

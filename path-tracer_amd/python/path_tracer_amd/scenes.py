@@ -54,8 +54,10 @@ def make_texture(size, seed, kind):
 
 
 class _Builder:
-    def __init__(self, seed):
+    def __init__(self, seed, dry=False):
         self.seed = seed
+        self.dry = dry            # count triangles only
+        self.triangle_count = 0
         self.positions, self.normals, self.uvs, self.indices = [], [], [], []
         self.materials = []
         self.vertex_count = 0
@@ -69,6 +71,9 @@ class _Builder:
 
     def add_patch(self, fn, nu, nv, material, uv_scale=(1.0, 1.0), jitter=1e-3, flip=False):
         """Tessellated parametric patch: fn(u, v) -> (N,3) positions for u, v in [0,1]; split to fit u16 indices."""
+        self.triangle_count += 2 * nu * nv
+        if self.dry:
+            return
         rows_per = max(1, min(nv, MAX_PRIMITIVE_VERTICES // (nu + 1) - 1))
         v0 = 0
         while v0 < nv:
@@ -210,10 +215,36 @@ def generate(kind="atrium", target_triangles=262144, seed=0xC0FFEE, texture_size
     for i in range(n_mr):
         textures.append(make_texture(texture_size, seed + 100 + i, "mr"))
 
+    # Tessellation scale: a patch of (nu x nv) quads is 2*nu*nv triangles; two dry (count-only) passes
+    # solve for the scale `s` that lands on the requested triangle count.
+    s = np.sqrt(max(target_triangles, 2048) / 262144.0)
+    for _ in range(3):
+        dry = _Builder(seed, dry=True)
+        _emit(dry, kind, s, np.random.default_rng(seed), n_albedo, n_mr)
+        s *= np.sqrt(max(target_triangles, 2048) / max(dry.triangle_count, 1))
     b = _Builder(seed)
-    # Budget bookkeeping: a patch of (nu x nv) quads is 2*nu*nv triangles.  `s` scales every tessellation.
-    base_total = 262144.0
-    s = np.sqrt(max(target_triangles, 2048) / base_total)
+    L = _emit(b, kind, s, rng, n_albedo, n_mr)
+
+    positions = np.concatenate(b.positions).astype(np.float32)
+    normals = np.concatenate(b.normals).astype(np.float32)
+    uvs = np.concatenate(b.uvs).astype(np.float32)
+    indices = np.concatenate(b.indices).astype(np.uint32)
+    materials = np.array(b.materials, dtype=MATERIAL_DTYPE)
+
+    vid = indices & np.uint32(0x00FFFFFF)
+    tri_pos = positions[vid.reshape(-1)].reshape(-1, 9)
+
+    if kind == "atrium":
+        cam = dict(pos=[-L * 0.42, 2.2, 0.6], target=[L * 0.3, 3.5, -0.4], v_fov=80.0, aperture=0.1, focus=10.0)
+    else:
+        cam = dict(pos=[-L * 0.45, 2.0, 1.0], target=[L * 0.35, 4.5, -0.8], v_fov=75.0, aperture=0.1, focus=10.0)
+    return dict(kind=kind, positions=positions.reshape(-1), normals=normals.reshape(-1), uvs=uvs.reshape(-1),
+                indices=indices.reshape(-1), materials=materials, textures=textures, triangles=np.ascontiguousarray(tri_pos),
+                camera=cam, primitive_count=b.prim_count)
+
+
+def _emit(b, kind, s, rng, n_albedo, n_mr):
+    """Lays the scene out into builder `b` at tessellation scale `s`; returns the scene length."""
 
     def q(n):
         return max(2, int(round(n * s)))
@@ -276,22 +307,7 @@ def generate(kind="atrium", target_triangles=262144, seed=0xC0FFEE, texture_size
                                     ([x0, hgt, zc - 3], [L / 8 - 2, 0, 0], [0, 0, 6], False)):
                 b.add_patch(_plane(o, eu, ev, wall_bump), q(48), q(48), _material(rng, n_albedo, n_mr), uv_scale=(3, 3), flip=fl)
 
-    positions = np.concatenate(b.positions).astype(np.float32)
-    normals = np.concatenate(b.normals).astype(np.float32)
-    uvs = np.concatenate(b.uvs).astype(np.float32)
-    indices = np.concatenate(b.indices).astype(np.uint32)
-    materials = np.array(b.materials, dtype=MATERIAL_DTYPE)
-
-    vid = indices & np.uint32(0x00FFFFFF)
-    tri_pos = positions[vid.reshape(-1)].reshape(-1, 9)
-
-    if kind == "atrium":
-        cam = dict(pos=[-L * 0.42, 2.2, 0.6], target=[L * 0.3, 3.5, -0.4], v_fov=80.0, aperture=0.1, focus=10.0)
-    else:
-        cam = dict(pos=[-L * 0.45, 2.0, 1.0], target=[L * 0.35, 4.5, -0.8], v_fov=75.0, aperture=0.1, focus=10.0)
-    return dict(kind=kind, positions=positions.reshape(-1), normals=normals.reshape(-1), uvs=uvs.reshape(-1),
-                indices=indices.reshape(-1), materials=materials, textures=textures, triangles=np.ascontiguousarray(tri_pos),
-                camera=cam, primitive_count=b.prim_count)
+    return L
 
 
 def tiny_scene(seed=1):
