@@ -99,12 +99,22 @@ int ptr_set_partition(ptr_ctx* ctx, uint32_t rank, uint32_t world, uint32_t stri
  *      "resolve" (output = sRGB-encoded accumulation.rgb / accumulation.a).  world = 1 turns it off. ---- */
 int ptr_set_sample_partition(ptr_ctx* ctx, uint32_t rank, uint32_t world);
 
+/* ---- tuning knobs (no counterpart in the reference); results never depend on them ----
+ *      "extend.refill"         idle lanes at which a persistent traversal wave fetches new rays: 8, 16 (default),
+ *                              32 or 64 (64 = only when the whole wave is idle)
+ *      "extend.leaf_weight"    1, 2 (default), 4, 8: how strongly lanes waiting at a leaf outvote lanes waiting at an
+ *                              inner node when the wave picks the step kind of its next iteration
+ *      "extend.blocks_per_cu"  persistent grid size of the traversal kernel, 1..6 blocks of 256 threads per CU */
+int ptr_set_option(ptr_ctx* ctx, const char* key, int value);
+
 /* ---- instrumentation (no counterpart in the reference) ---- */
 /* Per-pixel capture of the first two closest hits of the next "compute" dispatches: 16 bytes per pixel
  * {int32 prim0, float t0, int32 prim1, float t1}, prim = -1 for a miss / ended path.  0 = off. */
 int ptr_set_capture(ptr_ctx* ctx, ptr_handle buffer);
 /* Traversal counters: when on, "compute" dispatches run counting kernel variants.
- * out[0..4] = rays, node records fetched, triangle records fetched, shaded hits, frames. */
+ * out[0..4] = rays, node records fetched, triangle records fetched, shaded hits, frames;
+ * out[5..6] = wave-level inner-node / leaf iterations of the wavefront traversal (lane utilisation =
+ * node records / (64 * inner iterations)). */
 int ptr_stats_enable(ptr_ctx* ctx, int on);
 int ptr_stats_read(ptr_ctx* ctx, uint64_t out[8], int reset);
 /* Per-kernel device time from HIP events recorded around every launch on the context's stream. */

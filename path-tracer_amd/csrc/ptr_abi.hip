@@ -66,6 +66,9 @@ struct ptr_ctx {
     ptr::WavefrontScratch scratch{};
     void* scratch_block = nullptr;
     int cu_count = 256;
+    int opt_extend_leaf_weight = 2; // leaf lanes count this many times when a traversal wave picks its next step kind
+    int opt_extend_refill = 16;     // idle lanes that trigger a refill of the traversal wave (8, 16, 32, 48, 64)
+    int opt_extend_blocks_per_cu = 4;
     // small host->device writes (the per-frame 160-byte metadata) go through a ring of pinned slots so that
     // Buffer::write returns without draining the stream
     static constexpr int kStageSlots = 32;
@@ -169,10 +172,11 @@ void drain_profile(ptr_ctx* c) {
 
 // ---- wavefront scratch ----
 int ensure_scratch(ptr_ctx* c, uint32_t capacity) {
-    if (c->scratch.capacity >= capacity && c->scratch_block) return PTR_OK;
+    if (c->scratch.capacity >= capacity && c->scratch_block &&
+        c->scratch.extend_blocks == (uint32_t)c->cu_count * (uint32_t)c->opt_extend_blocks_per_cu) return PTR_OK;
     if (c->scratch_block) { PTR_HIP_CHECK(c, hipStreamSynchronize(c->stream)); PTR_HIP_CHECK(c, hipFree(c->scratch_block)); c->scratch_block = nullptr; }
     const size_t cap = ((size_t)capacity + 255) & ~(size_t)255;
-    const uint32_t extend_blocks = (uint32_t)c->cu_count * 4u;
+    const uint32_t extend_blocks = (uint32_t)c->cu_count * (uint32_t)c->opt_extend_blocks_per_cu;
     const size_t spill_words = (size_t)extend_blocks * (ptr::kExtendThreads / 64) * ptr::kStackSpill * 64;
     // 2 generations x (6 ray + 3 throughput + seed + pixel) words, hits + samples (4 words each), counters, spill
     const size_t words = cap * (2 * 11 + 8) + 64 + spill_words;
@@ -302,7 +306,9 @@ int dispatch_compute(ptr_ctx* c, const uint8_t constants[64], uint32_t gx, uint3
     const uint32_t domain_w = gx * 8u < meta.width ? gx * 8u : meta.width;
     const uint32_t domain_h = gy * 8u < meta.height ? gy * 8u : meta.height;
     if (domain_w == 0 || domain_h == 0) return PTR_OK;
-    if ((rc = ensure_scratch(c, meta.width * meta.height))) return rc;
+    // queue slots: whole 8x8 tiles of the owned rows (padded by one stripe); samples are indexed by pixel
+    const uint32_t padded = ((meta.width + 7u) / 8u) * ((meta.height + 7u) / 8u + c->part_stripe / 8u) * 64u;
+    if ((rc = ensure_scratch(c, padded > meta.width * meta.height ? padded : meta.width * meta.height))) return rc;
     const ptr::WavefrontScratch& w = c->scratch;
 
     PTR_HIP_CHECK(c, hipMemsetAsync(w.counters, 0, 64 * sizeof(uint32_t), c->stream));
@@ -314,7 +320,7 @@ int dispatch_compute(ptr_ctx* c, const uint8_t constants[64], uint32_t gx, uint3
             PTR_HIP_CHECK(c, hipMemsetAsync(w.counters + s, 0, 4, c->stream));
             PTR_HIP_CHECK(c, hipMemsetAsync(w.counters + ptr::kMaxBounceSlots + s, 0, 4, c->stream));
         }
-        { ScopedProfile prof(c, "wavefront.extend"); PTR_HIP_CHECK(c, ptr::launch_wf_extend(c->stream, fv, w, b, sv.stats)); }
+        { ScopedProfile prof(c, "wavefront.extend"); PTR_HIP_CHECK(c, ptr::launch_wf_extend(c->stream, fv, w, b, sv.stats, c->opt_extend_refill, c->opt_extend_leaf_weight)); }
         { ScopedProfile prof(c, "wavefront.shade"); PTR_HIP_CHECK(c, ptr::launch_wf_shade(c->stream, sv, w, b, meta.max_bounce, meta.min_bounce, domain_w, domain_h)); }
     }
     { ScopedProfile prof(c, "wavefront.accumulate"); PTR_HIP_CHECK(c, ptr::launch_wf_accumulate(c->stream, sv, w, domain_w, domain_h)); }
@@ -615,6 +621,26 @@ int ptr_set_sample_partition(ptr_ctx* c, uint32_t rank, uint32_t world) {
     if (world == 0 || rank >= world) return fail(c, PTR_E_INVALID, "ptr_set_sample_partition: rank %u / world %u", rank, world);
     c->sample_rank = rank; c->sample_world = world;
     return PTR_OK;
+}
+
+int ptr_set_option(ptr_ctx* c, const char* key, int value) {
+    if (!c || !key) return PTR_E_INVALID;
+    if (!strcmp(key, "extend.refill")) {
+        if (value != 8 && value != 16 && value != 32 && value != 64) return fail(c, PTR_E_INVALID, "extend.refill: 8, 16, 32 or 64 idle lanes");
+        c->opt_extend_refill = value;
+        return PTR_OK;
+    }
+    if (!strcmp(key, "extend.leaf_weight")) {
+        if (value != 1 && value != 2 && value != 4 && value != 8) return fail(c, PTR_E_INVALID, "extend.leaf_weight: 1, 2, 4 or 8");
+        c->opt_extend_leaf_weight = value;
+        return PTR_OK;
+    }
+    if (!strcmp(key, "extend.blocks_per_cu")) {
+        if (value < 1 || value > 6) return fail(c, PTR_E_INVALID, "extend.blocks_per_cu: 1..6 (24 KiB of LDS per block)");
+        c->opt_extend_blocks_per_cu = value;
+        return PTR_OK;
+    }
+    return fail(c, PTR_E_INVALID, "ptr_set_option: unknown key '%s'", key);
 }
 
 int ptr_set_capture(ptr_ctx* c, ptr_handle buffer) {

@@ -18,29 +18,30 @@ namespace ptr {
 
 constexpr float kBoxPad = 1.0000002384185791015625f;  // 1 + 2^-22: boxes cull conservatively
 
-// Appends the lanes with `keep` set to a queue: returns the slot for this lane (undefined when !keep).
-PTR_DEV uint32_t wave_append(uint32_t* counter, bool keep) {
-    const unsigned long long mask = __ballot(keep);
-    if (mask == 0ull) return 0u;
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t leader = (uint32_t)__builtin_ctzll(mask);
-    uint32_t base = 0u;
-    if (lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(mask));
-    base = __shfl(base, (int)leader);
-    return base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-}
+constexpr uint32_t kInvalidPixel = 0xffffffffu;  // queue slot that holds no path (frame edge / foreign stripe)
 
 // ---- generate ------------------------------------------------------------------------------------------
+// One wave per 8x8 tile of the rows this GPU owns; slot = wave * 64 + lane, so the primary-ray queue needs
+// no atomics and a wave's 64 rays are one screen tile (coherent traversal).  Lanes outside the frame keep
+// their slot but mark it invalid.
 __global__ __launch_bounds__(256) void ptr_wf_generate(SceneView sv, WavefrontScratch w, uint32_t domain_w, uint32_t domain_h,
-                                                      uint32_t tiles_x) {
+                                                      uint32_t tiles_x, uint32_t owned_tile_rows) {
     const SceneMeta& m = *sv.meta;
-    const uint32_t wave = blockIdx.x * 4u + (threadIdx.x >> 6);  // one 8x8 tile per wave
+    const uint32_t wave = blockIdx.x * 4u + (threadIdx.x >> 6);
     const uint32_t lane = threadIdx.x & 63u;
+    if (wave >= tiles_x * owned_tile_rows) return;
+    if (wave == 0u && lane == 0u) w.counters[0] = tiles_x * owned_tile_rows * 64u;
+    const uint32_t j = wave / tiles_x;  // j-th tile row owned by this GPU
+    uint32_t tile_row = j;
+    if (sv.part_world > 1u) {
+        const uint32_t rows_per_stripe = sv.part_stripe_rows / 8u;
+        tile_row = ((j / rows_per_stripe) * sv.part_world + sv.part_rank) * rows_per_stripe + j % rows_per_stripe;
+    }
     const uint32_t gx = (wave % tiles_x) * 8u + (lane & 7u);
-    const uint32_t gy = (wave / tiles_x) * 8u + (lane >> 3);
-    const bool valid = gx < domain_w && gy < domain_h && owns_row(sv, gy);
+    const uint32_t gy = tile_row * 8u + (lane >> 3);
+    const bool valid = gx < domain_w && gy < domain_h;
 
-    Ray r; r.origin = mk3(0, 0, 0); r.dir = mk3(0, 0, 0);
+    Ray r; r.origin = mk3(0, 0, 0); r.dir = mk3(0, 0, 1);
     uint32_t seed = 0u;
     if (valid) {
         const int32_t cx = (int32_t)gx * m.downscale_factor, cy = (int32_t)gy * m.downscale_factor;
@@ -48,13 +49,12 @@ __global__ __launch_bounds__(256) void ptr_wf_generate(SceneView sv, WavefrontSc
         r = generate_camera_ray(m, cx, cy, seed);  // seed by value: the bounce loop restarts from it
         if (sv.capture) { Capture c; c.prim0 = -1; c.t0 = 0.0f; c.prim1 = -1; c.t1 = 0.0f; sv.capture[(size_t)gy * m.width + gx] = c; }
     }
-    const uint32_t slot = wave_append(&w.counters[0], valid);
-    if (!valid) return;
+    const uint32_t slot = wave * 64u + lane;
     w.ray[0][0][slot] = r.origin.x; w.ray[0][1][slot] = r.origin.y; w.ray[0][2][slot] = r.origin.z;
     w.ray[0][3][slot] = r.dir.x; w.ray[0][4][slot] = r.dir.y; w.ray[0][5][slot] = r.dir.z;
     w.throughput[0][0][slot] = 1.0f; w.throughput[0][1][slot] = 1.0f; w.throughput[0][2][slot] = 1.0f;
     w.seed[0][slot] = seed;
-    w.pixel[0][slot] = gy * m.width + gx;
+    w.pixel[0][slot] = valid ? gy * m.width + gx : kInvalidPixel;
 }
 
 // ---- extend --------------------------------------------------------------------------------------------
@@ -71,7 +71,22 @@ PTR_DEV SlabResult slab(const float4 lo, const float4 hi, const f3 o, const f3 i
     return s;
 }
 
-template <bool STATS>
+constexpr int32_t kTraversalDone = INT32_MIN;  // never a leaf reference: triangle counts stay below 2^29
+
+// Persistent wave64 traversal.
+//   * Work assignment: wave g of the G resident waves owns the 64-ray batches g, g+G, g+2G, ... of the queue
+//     and walks them with a private cursor -- no atomics (one address sustains only ~90 atomics/us), and the
+//     batches of a wave are spread over the whole frame, which evens out the load.
+//   * Ballot-driven refill: whenever at least REFILL lanes are idle (their ray finished) and the wave still owns
+//     unread rays, the idle lanes fetch the next rays of the wave's list; a wave therefore keeps most lanes
+//     busy instead of draining a batch down to its slowest ray.  (The memory pipeline's cost is per wave
+//     instruction, not per active lane, so lane utilisation is what buys throughput.)
+//   * Majority scheduling: a lane is either at an inner node or at a leaf.  Each wave iteration executes ONE of
+//     the two step kinds, the one more lanes are waiting for (leaves are favoured by the factor LEAF_WEIGHT: a
+//     leaf hit shortens the ray and culls later nodes); the other lanes keep their state and wait.  A ray's own
+//     sequence of steps never changes, only when it is executed.
+//   * Per-lane stack: kStackLds entries in LDS (lane-interleaved, conflict-free), deeper entries in global memory.
+template <bool STATS, int REFILL, int LEAF_WEIGHT>
 __global__ __launch_bounds__(kExtendThreads, 4) void ptr_wf_extend(FlatView fv, WavefrontScratch w, uint32_t gen, uint32_t slot_b,
                                                                 unsigned long long* stats) {
     __shared__ int32_t lds_stack[(kExtendThreads / 64) * kStackLds * 64];
@@ -81,70 +96,111 @@ __global__ __launch_bounds__(kExtendThreads, 4) void ptr_wf_extend(FlatView fv, 
     int32_t* my_spill = w.stack_spill + (size_t)(blockIdx.x * (kExtendThreads / 64) + wave_in_block) * kStackSpill * 64 + lane;
 
     const uint32_t count = w.counters[slot_b];
-    uint32_t* cursor = &w.counters[kMaxBounceSlots + slot_b];
+    const uint32_t global_wave = blockIdx.x * (kExtendThreads / 64) + wave_in_block;
+    const uint32_t total_waves = gridDim.x * (kExtendThreads / 64);
+    const uint32_t batches = (count + 63u) / 64u;
+    const uint32_t my_batches = batches > global_wave ? (batches - global_wave + total_waves - 1u) / total_waves : 0u;
+    const uint32_t my_rays = my_batches * 64u;  // entries past `count` or marked invalid are skipped when read
+    uint32_t next_k = 0u;                       // wave-uniform: rays of my list already handed to lanes
     unsigned long long n_rays = 0, n_nodes = 0, n_tris = 0;
+    unsigned long long wave_inner_steps = 0, wave_leaf_steps = 0;  // wave-uniform: iterations of each kind
+
+    const float min_t = 0.001f;
+    uint32_t slot = kInvalidPixel;              // queue slot this lane is tracing; kInvalidPixel = idle
+    f3 o = mk3(0, 0, 0), d = mk3(0, 0, 1), inv = mk3(0, 0, 1);
+    float best_t = 1e15f, best_u = 0.0f, best_v = 0.0f;
+    int32_t best_rank = -1, best_prim = -1;
+    int32_t cur = kTraversalDone;
+    uint32_t sp = 0u;
 
     for (;;) {
-        uint32_t base = 0u;
-        if (lane == 0u) base = atomicAdd(cursor, 64u);
-        base = __shfl(base, 0);
-        if (base >= count) break;
-        const uint32_t slot = base + lane;
-        if (slot < count) {
-            const f3 o = mk3(w.ray[gen][0][slot], w.ray[gen][1][slot], w.ray[gen][2][slot]);
-            const f3 d = mk3(w.ray[gen][3][slot], w.ray[gen][4][slot], w.ray[gen][5][slot]);
-            const f3 inv = mk3(rcp(d.x), rcp(d.y), rcp(d.z));
-            const float min_t = 0.001f;
-            float best_t = 1e15f, best_u = 0.0f, best_v = 0.0f;
-            int32_t best_rank = -1, best_prim = -1;
-            int32_t cur = fv.root;
-            uint32_t sp = 0u;
-            if (STATS) n_rays++;
-            for (;;) {
-                if (cur >= 0) {
-                    const float4 q0 = fv.nodes[4 * cur], q1 = fv.nodes[4 * cur + 1];
-                    const float4 q2 = fv.nodes[4 * cur + 2], q3 = fv.nodes[4 * cur + 3];
-                    if (STATS) n_nodes++;
-                    const SlabResult l = slab(q0, q1, o, inv, min_t, best_t);
-                    const SlabResult r = slab(q2, q3, o, inv, min_t, best_t);
-                    const int32_t left = __float_as_int(q0.w), right = __float_as_int(q1.w);
-                    if (l.hit && r.hit) {
-                        const bool right_first = r.entry < l.entry;
-                        const int32_t far_ref = right_first ? left : right;
-                        if (sp < kStackLds) my_lds[sp * 64u] = far_ref;
-                        else my_spill[(sp - kStackLds) * 64u] = far_ref;
-                        sp++;
-                        cur = right_first ? right : left;
-                        continue;
-                    }
-                    if (l.hit) { cur = left; continue; }
-                    if (r.hit) { cur = right; continue; }
-                } else {
-                    const uint32_t ref = (uint32_t)~cur;
-                    const uint32_t first = ref >> 2, tri_count = (ref & 3u) + 1u;
-                    for (uint32_t k = 0; k < tri_count; k++) {
-                        const float4* tr = fv.triangles + 4 * (size_t)(first + k);
-                        const float4 a = tr[0], b = tr[1], c = tr[2], n4 = tr[3];
-                        if (STATS) n_tris++;
-                        const f3 e1 = mk3(b.x, b.y, b.z), e2 = mk3(c.x, c.y, c.z), n = mk3(n4.x, n4.y, n4.z);
-                        const f3 ov = o - mk3(a.x, a.y, a.z);
-                        const f3 q = cross(ov, d);
-                        const float dd = rcp(dot(d, n));
-                        const float u = dd * dot(-q, e2);
-                        const float v = dd * dot(q, e1);
-                        const float t = dd * dot(-n, ov);
-                        if (u < 0.0f || u > 1.0f || v < 0.0f || u + v > 1.0f || t < min_t || t > best_t) continue;
-                        if (t != t || u != u || v != v) continue;
-                        const int32_t rank = __float_as_int(a.w);
-                        if (best_prim >= 0 && t == best_t && rank < best_rank) continue;
-                        best_t = t; best_u = u; best_v = v; best_rank = rank; best_prim = __float_as_int(b.w);
+        const unsigned long long idle = __ballot(slot == kInvalidPixel);
+        if (idle != 0ull && next_k < my_rays && ((uint32_t)__popcll(idle) >= (uint32_t)REFILL || idle == ~0ull)) {
+            if (slot == kInvalidPixel) {
+                const uint32_t k = next_k + (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
+                if (k < my_rays) {
+                    const uint32_t idx = ((k >> 6) * total_waves + global_wave) * 64u + (k & 63u);
+                    if (idx < count && w.pixel[gen][idx] != kInvalidPixel) {
+                        slot = idx;
+                        o = mk3(w.ray[gen][0][idx], w.ray[gen][1][idx], w.ray[gen][2][idx]);
+                        d = mk3(w.ray[gen][3][idx], w.ray[gen][4][idx], w.ray[gen][5][idx]);
+                        inv = mk3(rcp(d.x), rcp(d.y), rcp(d.z));
+                        best_t = 1e15f; best_u = 0.0f; best_v = 0.0f; best_rank = -1; best_prim = -1;
+                        cur = fv.root; sp = 0u;
+                        if (STATS) n_rays++;
                     }
                 }
-                if (sp == 0u) break;
+            }
+            next_k += (uint32_t)__popcll(idle);
+            continue;  // re-evaluate: skipped entries leave lanes idle
+        }
+        if (idle == ~0ull) break;  // nothing in flight and my list is exhausted
+
+        const bool at_inner = slot != kInvalidPixel && cur >= 0;
+        const bool at_leaf = slot != kInvalidPixel && cur < 0;
+        const uint32_t n_inner = (uint32_t)__popcll(__ballot(at_inner));
+        const uint32_t n_leaf = (uint32_t)__popcll(__ballot(at_leaf));
+        const bool leaf_turn = n_leaf * (uint32_t)LEAF_WEIGHT > n_inner;
+        if (STATS) { if (leaf_turn) wave_leaf_steps++; else wave_inner_steps++; }
+
+        if (!leaf_turn && at_inner) {  // one inner-node step
+            const float4 q0 = fv.nodes[4 * cur], q1 = fv.nodes[4 * cur + 1];
+            const float4 q2 = fv.nodes[4 * cur + 2], q3 = fv.nodes[4 * cur + 3];
+            if (STATS) n_nodes++;
+            const SlabResult l = slab(q0, q1, o, inv, min_t, best_t);
+            const SlabResult r = slab(q2, q3, o, inv, min_t, best_t);
+            const int32_t left = __float_as_int(q0.w), right = __float_as_int(q1.w);
+            if (l.hit && r.hit) {
+                const bool right_first = r.entry < l.entry;
+                const int32_t far_ref = right_first ? left : right;
+                if (sp < kStackLds) my_lds[sp * 64u] = far_ref;
+                else my_spill[(sp - kStackLds) * 64u] = far_ref;
+                sp++;
+                cur = right_first ? right : left;
+            } else if (l.hit) {
+                cur = left;
+            } else if (r.hit) {
+                cur = right;
+            } else if (sp == 0u) {
+                cur = kTraversalDone;
+            } else {
                 sp--;
                 cur = sp < kStackLds ? my_lds[sp * 64u] : my_spill[(sp - kStackLds) * 64u];
             }
+        }
+
+        if (leaf_turn && at_leaf) {  // all triangles of one leaf
+            const uint32_t ref = (uint32_t)~cur;
+            const uint32_t first = ref >> 2, tri_count = (ref & 3u) + 1u;
+            for (uint32_t k = 0; k < tri_count; k++) {
+                const float4* tr = fv.triangles + 4 * (size_t)(first + k);
+                const float4 a = tr[0], b = tr[1], c = tr[2], n4 = tr[3];
+                if (STATS) n_tris++;
+                const f3 e1 = mk3(b.x, b.y, b.z), e2 = mk3(c.x, c.y, c.z), n = mk3(n4.x, n4.y, n4.z);
+                const f3 ov = o - mk3(a.x, a.y, a.z);
+                const f3 q = cross(ov, d);
+                const float dd = rcp(dot(d, n));
+                const float u = dd * dot(-q, e2);
+                const float v = dd * dot(q, e1);
+                const float t = dd * dot(-n, ov);
+                if (u < 0.0f || u > 1.0f || v < 0.0f || u + v > 1.0f || t < min_t || t > best_t) continue;
+                if (t != t || u != u || v != v) continue;
+                const int32_t rank = __float_as_int(a.w);
+                if (best_prim >= 0 && t == best_t && rank < best_rank) continue;
+                best_t = t; best_u = u; best_v = v; best_rank = rank; best_prim = __float_as_int(b.w);
+            }
+            if (sp == 0u) {
+                cur = kTraversalDone;
+            } else {
+                sp--;
+                cur = sp < kStackLds ? my_lds[sp * 64u] : my_spill[(sp - kStackLds) * 64u];
+            }
+        }
+
+        // finished rays publish their hit and free the lane
+        if (slot != kInvalidPixel && cur == kTraversalDone) {
             w.hits[slot] = make_float4(best_t, best_u, best_v, __int_as_float(best_prim));
+            slot = kInvalidPixel;
         }
     }
     if (STATS && stats) {
@@ -153,31 +209,42 @@ __global__ __launch_bounds__(kExtendThreads, 4) void ptr_wf_extend(FlatView fv, 
             n_nodes += __shfl_down(n_nodes, off);
             n_tris += __shfl_down(n_tris, off);
         }
-        if (lane == 0u) { atomicAdd(&stats[0], n_rays); atomicAdd(&stats[1], n_nodes); atomicAdd(&stats[2], n_tris); }
+        if (lane == 0u) {
+            atomicAdd(&stats[0], n_rays); atomicAdd(&stats[1], n_nodes); atomicAdd(&stats[2], n_tris);
+            atomicAdd(&stats[5], wave_inner_steps); atomicAdd(&stats[6], wave_leaf_steps);
+        }
     }
 }
 
 // ---- shade ---------------------------------------------------------------------------------------------
+constexpr uint32_t kShadeThreads = 1024;
+
+// Survivors of a 1024-lane block are compacted with ONE atomic on the next queue's counter: ballots give the
+// per-wave counts, lane 0 of the block turns them into offsets.  (A single address sustains only ~90 atomics
+// per microsecond, so per-wave appends would bound the kernel.)
 template <bool STATS>
-__global__ __launch_bounds__(256) void ptr_wf_shade(SceneView sv, WavefrontScratch w, uint32_t gen, uint32_t slot_b, uint32_t slot_next,
-                                                   uint32_t bounce, uint32_t max_bounce, uint32_t min_bounce) {
+__global__ __launch_bounds__(kShadeThreads) void ptr_wf_shade(SceneView sv, WavefrontScratch w, uint32_t gen, uint32_t slot_b,
+                                                             uint32_t slot_next, uint32_t bounce, uint32_t max_bounce, uint32_t min_bounce) {
+    __shared__ uint32_t wave_offset[kShadeThreads / 64];
+    __shared__ uint32_t block_base;
     const uint32_t count = w.counters[slot_b];
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    const uint32_t wave_base = i & ~63u;
-    if (wave_base >= count) return;  // whole wave idle
-    const bool live = i < count;
+    if (blockIdx.x * kShadeThreads >= count) return;  // uniform for the block
+    const uint32_t i = blockIdx.x * kShadeThreads + threadIdx.x;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint32_t pixel = kInvalidPixel;
+    if (i < count) pixel = w.pixel[gen][i];
+    const bool live = pixel != kInvalidPixel;
 
     bool go_on = false;
     Ray r; r.origin = mk3(0, 0, 0); r.dir = mk3(0, 0, 0); r.min_t = 0.001f; r.max_t = 1e15f;
     f3 throughput = mk3(0, 0, 0), result = mk3(0, 0, 0);
-    uint32_t seed = 0u, pixel = 0u;
+    uint32_t seed = 0u;
     unsigned long long shaded = 0;
     if (live) {
         r.origin = mk3(w.ray[gen][0][i], w.ray[gen][1][i], w.ray[gen][2][i]);
         r.dir = mk3(w.ray[gen][3][i], w.ray[gen][4][i], w.ray[gen][5][i]);
         throughput = mk3(w.throughput[gen][0][i], w.throughput[gen][1][i], w.throughput[gen][2][i]);
         seed = w.seed[gen][i];
-        pixel = w.pixel[gen][i];
         const float4 h4 = w.hits[i];
         Hit h; h.t = h4.x; h.u = h4.y; h.v = h4.z; h.prim = __float_as_int(h4.w);
         if (STATS && h.prim >= 0) shaded = 1;
@@ -190,9 +257,19 @@ __global__ __launch_bounds__(256) void ptr_wf_shade(SceneView sv, WavefrontScrat
         if (go_on && bounce + 1u >= max_bounce) { go_on = false; result = mk3(0.0f, 0.0f, 0.0f); }  // loop exhausted: radiance
         if (!go_on) w.samples[pixel] = make_float4(result.x, result.y, result.z, 1.0f);
     }
-    const uint32_t next = gen ^ 1u;
-    const uint32_t slot = wave_append(&w.counters[slot_next], go_on);
+
+    const unsigned long long mask = __ballot(go_on);
+    if (lane == 0u) wave_offset[wave] = (uint32_t)__popcll(mask);
+    __syncthreads();
+    if (threadIdx.x == 0u) {
+        uint32_t total = 0u;
+        for (uint32_t k = 0; k < kShadeThreads / 64; k++) { const uint32_t n = wave_offset[k]; wave_offset[k] = total; total += n; }
+        block_base = total ? atomicAdd(&w.counters[slot_next], total) : 0u;
+    }
+    __syncthreads();
     if (go_on) {
+        const uint32_t next = gen ^ 1u;
+        const uint32_t slot = block_base + wave_offset[wave] + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
         w.ray[next][0][slot] = r.origin.x; w.ray[next][1][slot] = r.origin.y; w.ray[next][2][slot] = r.origin.z;
         w.ray[next][3][slot] = r.dir.x; w.ray[next][4][slot] = r.dir.y; w.ray[next][5][slot] = r.dir.z;
         w.throughput[next][0][slot] = throughput.x; w.throughput[next][1][slot] = throughput.y; w.throughput[next][2][slot] = throughput.z;
@@ -201,7 +278,7 @@ __global__ __launch_bounds__(256) void ptr_wf_shade(SceneView sv, WavefrontScrat
     }
     if (STATS && sv.stats) {
         for (int off = 32; off > 0; off >>= 1) shaded += __shfl_down(shaded, off);
-        if ((threadIdx.x & 63u) == 0u && shaded) atomicAdd(&sv.stats[3], shaded);
+        if (lane == 0u && shaded) atomicAdd(&sv.stats[3], shaded);
     }
 }
 
@@ -227,28 +304,58 @@ static inline uint32_t tile_blocks(uint32_t domain_w, uint32_t domain_h, uint32_
 }
 
 hipError_t launch_wf_generate(hipStream_t s, const SceneView& sv, const WavefrontScratch& w, uint32_t domain_w, uint32_t domain_h) {
-    uint32_t tiles_x;
-    const uint32_t blocks = tile_blocks(domain_w, domain_h, tiles_x);
-    if (blocks == 0) return hipSuccess;
-    hipLaunchKernelGGL(ptr_wf_generate, dim3(blocks), dim3(256), 0, s, sv, w, domain_w, domain_h, tiles_x);
+    const uint32_t tiles_x = (domain_w + 7u) / 8u;
+    uint32_t owned_tile_rows = (domain_h + 7u) / 8u;
+    if (sv.part_world > 1u) {
+        const uint32_t rows_per_stripe = sv.part_stripe_rows / 8u;
+        const uint32_t stripes = (owned_tile_rows + rows_per_stripe - 1u) / rows_per_stripe;
+        const uint32_t owned = stripes > sv.part_rank ? (stripes - sv.part_rank + sv.part_world - 1u) / sv.part_world : 0u;
+        owned_tile_rows = owned * rows_per_stripe;
+    }
+    const uint32_t waves = tiles_x * owned_tile_rows;
+    // the kernel publishes the queue length; with nothing owned, leave the zeroed counter alone
+    if (waves == 0) return hipSuccess;
+    hipLaunchKernelGGL(ptr_wf_generate, dim3((waves + 3u) / 4u), dim3(256), 0, s, sv, w, domain_w, domain_h, tiles_x, owned_tile_rows);
     return hipGetLastError();
 }
 
-hipError_t launch_wf_extend(hipStream_t s, const FlatView& fv, const WavefrontScratch& w, uint32_t bounce, unsigned long long* stats) {
+template <bool STATS, int LEAF_WEIGHT>
+static void launch_extend_variant(hipStream_t s, const FlatView& fv, const WavefrontScratch& w, uint32_t bounce, unsigned long long* stats,
+                                  int refill) {
     const uint32_t slot_b = bounce % kMaxBounceSlots;
-    if (stats) hipLaunchKernelGGL(ptr_wf_extend<true>, dim3(w.extend_blocks), dim3(kExtendThreads), 0, s, fv, w, bounce & 1u, slot_b, stats);
-    else hipLaunchKernelGGL(ptr_wf_extend<false>, dim3(w.extend_blocks), dim3(kExtendThreads), 0, s, fv, w, bounce & 1u, slot_b, stats);
+    const dim3 grid(w.extend_blocks), block(kExtendThreads);
+    switch (refill) {
+    case 8: hipLaunchKernelGGL((ptr_wf_extend<STATS, 8, LEAF_WEIGHT>), grid, block, 0, s, fv, w, bounce & 1u, slot_b, stats); break;
+    case 16: hipLaunchKernelGGL((ptr_wf_extend<STATS, 16, LEAF_WEIGHT>), grid, block, 0, s, fv, w, bounce & 1u, slot_b, stats); break;
+    case 32: hipLaunchKernelGGL((ptr_wf_extend<STATS, 32, LEAF_WEIGHT>), grid, block, 0, s, fv, w, bounce & 1u, slot_b, stats); break;
+    default: hipLaunchKernelGGL((ptr_wf_extend<STATS, 64, LEAF_WEIGHT>), grid, block, 0, s, fv, w, bounce & 1u, slot_b, stats); break;
+    }
+}
+
+hipError_t launch_wf_extend(hipStream_t s, const FlatView& fv, const WavefrontScratch& w, uint32_t bounce, unsigned long long* stats,
+                            int refill, int leaf_weight) {
+    if (stats) {
+        launch_extend_variant<true, 2>(s, fv, w, bounce, stats, refill);
+    } else {
+        switch (leaf_weight) {
+        case 1: launch_extend_variant<false, 1>(s, fv, w, bounce, stats, refill); break;
+        case 4: launch_extend_variant<false, 4>(s, fv, w, bounce, stats, refill); break;
+        case 8: launch_extend_variant<false, 8>(s, fv, w, bounce, stats, refill); break;
+        default: launch_extend_variant<false, 2>(s, fv, w, bounce, stats, refill); break;
+        }
+    }
     return hipGetLastError();
 }
 
 hipError_t launch_wf_shade(hipStream_t s, const SceneView& sv, const WavefrontScratch& w, uint32_t bounce, uint32_t max_bounce,
                            uint32_t min_bounce, uint32_t domain_w, uint32_t domain_h) {
-    const uint32_t upper = domain_w * domain_h;  // live paths never exceed the pixel count
-    const uint32_t blocks = (upper + 255u) / 256u;
+    // queue slots never exceed the padded tile count of the frame
+    const uint32_t upper = ((domain_w + 7u) / 8u) * ((domain_h + 7u) / 8u + sv.part_stripe_rows / 8u) * 64u;
+    const uint32_t blocks = (upper + kShadeThreads - 1u) / kShadeThreads;
     if (blocks == 0) return hipSuccess;
     const uint32_t slot_b = bounce % kMaxBounceSlots, slot_next = (bounce + 1u) % kMaxBounceSlots;
-    if (sv.stats) hipLaunchKernelGGL(ptr_wf_shade<true>, dim3(blocks), dim3(256), 0, s, sv, w, bounce & 1u, slot_b, slot_next, bounce, max_bounce, min_bounce);
-    else hipLaunchKernelGGL(ptr_wf_shade<false>, dim3(blocks), dim3(256), 0, s, sv, w, bounce & 1u, slot_b, slot_next, bounce, max_bounce, min_bounce);
+    if (sv.stats) hipLaunchKernelGGL(ptr_wf_shade<true>, dim3(blocks), dim3(kShadeThreads), 0, s, sv, w, bounce & 1u, slot_b, slot_next, bounce, max_bounce, min_bounce);
+    else hipLaunchKernelGGL(ptr_wf_shade<false>, dim3(blocks), dim3(kShadeThreads), 0, s, sv, w, bounce & 1u, slot_b, slot_next, bounce, max_bounce, min_bounce);
     return hipGetLastError();
 }
 

@@ -62,6 +62,7 @@ def lib():
         "ptr_dispatch": [vp, C.c_char_p, vp, u32, u32, u32],
         "ptr_set_partition": [vp, u32, u32, u32],
         "ptr_set_sample_partition": [vp, u32, u32],
+        "ptr_set_option": [vp, C.c_char_p, C.c_int],
         "ptr_set_capture": [vp, u32],
         "ptr_stats_enable": [vp, C.c_int],
         "ptr_stats_read": [vp, P(u64), C.c_int],
@@ -83,7 +84,7 @@ ABI_SYMBOLS = ["ptr_ctx_create", "ptr_ctx_destroy", "ptr_ctx_set_stream", "ptr_l
                "ptr_buffer_destroy", "ptr_buffer_write", "ptr_buffer_read", "ptr_buffer_address", "ptr_sampler_create",
                "ptr_image_create", "ptr_image_wrap", "ptr_image_destroy", "ptr_image_upload", "ptr_image_read",
                "ptr_image_index", "ptr_sampler_index", "ptr_image_address", "ptr_bvh_bind_flat", "ptr_dispatch",
-               "ptr_set_partition", "ptr_set_sample_partition", "ptr_set_capture", "ptr_stats_enable", "ptr_stats_read", "ptr_profile_enable",
+               "ptr_set_partition", "ptr_set_sample_partition", "ptr_set_option", "ptr_set_capture", "ptr_stats_enable", "ptr_stats_read", "ptr_profile_enable",
                "ptr_profile_read", "ptr_profile_names"]
 
 
@@ -143,6 +144,9 @@ class Context:
     def set_sample_partition(self, rank, world):
         self._check(self._L.ptr_set_sample_partition(self.handle, rank, world))
 
+    def set_option(self, key, value):
+        self._check(self._L.ptr_set_option(self.handle, key.encode(), int(value)))
+
     def set_capture(self, buffer):
         self._check(self._L.ptr_set_capture(self.handle, buffer.handle if buffer is not None else 0))
 
@@ -152,7 +156,8 @@ class Context:
     def stats_read(self, reset=True):
         out = (C.c_uint64 * 8)()
         self._check(self._L.ptr_stats_read(self.handle, out, 1 if reset else 0))
-        return dict(rays=int(out[0]), nodes=int(out[1]), triangles=int(out[2]), shaded=int(out[3]), frames=int(out[4]))
+        return dict(rays=int(out[0]), nodes=int(out[1]), triangles=int(out[2]), shaded=int(out[3]), frames=int(out[4]),
+                    wave_inner_steps=int(out[5]), wave_leaf_steps=int(out[6]))
 
     def profile_enable(self, on):
         self._check(self._L.ptr_profile_enable(self.handle, 1 if on else 0))

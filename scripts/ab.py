@@ -1,0 +1,65 @@
+#!/usr/bin/env python3
+"""A/B timing of tuning knobs in ONE process (interleaved rounds, same scene, same GPU):
+   python scripts/ab.py --configs "extend.fetch=0" "extend.fetch=1" "extend.fetch=0,extend.blocks_per_cu=6"
+Prints per-config median / min ms per frame and the per-kernel split from the library's HIP-event profiler."""
+import argparse
+import json
+import os
+import statistics
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "path-tracer_amd", "python"))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--configs", nargs="+", default=["extend.fetch=0", "extend.fetch=1"])
+    ap.add_argument("--rounds", type=int, default=5)
+    ap.add_argument("--frames", type=int, default=20)
+    ap.add_argument("--triangles", type=int, default=2_800_000)
+    ap.add_argument("--scene", default="street_exterior")
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--bounces", type=int, default=4)
+    ap.add_argument("--texture-size", type=int, default=512)
+    ap.add_argument("--pipeline", default="compute")
+    args = ap.parse_args()
+    import bench
+    from path_tracer_amd import hip
+    sc, nodes, flat, meta, _ = bench.build_scene(args, 0)
+    ctx = hip.Context(0)
+    gpu = hip.GpuScene(ctx, sc, nodes, flat, meta)
+    loop = hip.FrameLoop(ctx, gpu, args.width, args.height, args.pipeline)
+    configs = [dict((kv.split("=")[0], int(kv.split("=")[1])) for kv in c.split(",") if kv) for c in args.configs]
+    times = [[] for _ in configs]
+    kernels = [{} for _ in configs]
+    for rnd in range(args.rounds + 1):
+        for i, cfg in enumerate(configs):
+            for k, v in cfg.items():
+                ctx.set_option(k, v)
+            loop.reset()
+            loop.frame(); ctx.sync()                     # settle (scratch re-allocation, clocks)
+            ctx.profile_read(reset=True); ctx.profile_enable(True)
+            t0 = time.perf_counter()
+            for _ in range(args.frames):
+                loop.frame()
+            ctx.sync()
+            dt = (time.perf_counter() - t0) / args.frames * 1e3
+            ctx.profile_enable(False)
+            prof = ctx.profile_read(reset=True)
+            if rnd == 0:
+                continue                                 # first round is warm-up
+            times[i].append(dt)
+            for n, v in prof.items():
+                kernels[i].setdefault(n, []).append(v["total_ms"] / args.frames)
+    for i, cfg in enumerate(configs):
+        print(json.dumps(dict(config=args.configs[i], median_ms=round(statistics.median(times[i]), 4), min_ms=round(min(times[i]), 4),
+                              kernels_ms={n: round(statistics.median(v), 4) for n, v in sorted(kernels[i].items())})), flush=True)
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()
