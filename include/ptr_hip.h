@@ -102,9 +102,11 @@ int ptr_set_sample_partition(ptr_ctx* ctx, uint32_t rank, uint32_t world);
 /* ---- tuning knobs (no counterpart in the reference); results never depend on them ----
  *      "extend.refill"         idle lanes at which a persistent traversal wave fetches new rays: 8, 16 (default),
  *                              32 or 64 (64 = only when the whole wave is idle)
- *      "extend.leaf_weight"    1, 2 (default), 4, 8: how strongly lanes waiting at a leaf outvote lanes waiting at an
+ *      "extend.inner_reps"     1..3 inner-node steps per inner turn of a traversal wave
+ *      "extend.leaf_all"       1 (default): a leaf turn tests the lane's whole leaf; 0: one triangle per turn
+ *      "extend.leaf_weight"    1, 2 (default), 4: how strongly lanes waiting at a leaf outvote lanes waiting at an
  *                              inner node when the wave picks the step kind of its next iteration
- *      "extend.blocks_per_cu"  persistent grid size of the traversal kernel, 1..6 blocks of 256 threads per CU */
+ *      "extend.blocks_per_cu"  persistent grid size of the traversal kernel, 1..8 blocks of 256 threads per CU (default 8) */
 int ptr_set_option(ptr_ctx* ctx, const char* key, int value);
 
 /* ---- instrumentation (no counterpart in the reference) ---- */

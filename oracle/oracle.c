@@ -377,10 +377,10 @@ static uint32_t hit_aabbs(const orc_frame* f, const ray_t* r) {
 
 /* ------------------------------------------------------------------------------------------------
  * Closest hit over the flattened GPU layout.  This restates THIS REPOSITORY's traversal (not the
- * reference's): near-child-first with an explicit stack, boxes padded by (1 + 2^-22) on the exit
- * distance so they cull conservatively, leaves of 1..4 pre-gathered triangles, equal-t ties resolved
- * by the triangle's rank in the reference visiting order (later-visited wins, as ray.h:153 does),
- * NaN-t candidates rejected.  Used to count the nodes/triangles the GPU kernels fetch and to check
+ * reference's): 4-wide nodes with 8-bit quantised child boxes, children visited nearest first through an
+ * explicit stack, boxes padded by (1 + 2^-22) on the exit distance so they cull conservatively, leaves of
+ * 1..4 pre-gathered triangles, equal-t ties resolved by the triangle's rank in the reference visiting
+ * order (later-visited wins, as ray.h:153 does), NaN-t candidates rejected.  Used to count the nodes/triangles the GPU kernels fetch and to check
  * the flattened layout without a GPU.
  * ---------------------------------------------------------------------------------------------- */
 typedef struct {
@@ -390,10 +390,10 @@ typedef struct {
     float scene_min[3], scene_max[3];
 } flat_header_t;
 typedef struct {
-    float lmin[3]; int32_t left;
-    float lmax[3]; int32_t right;
-    float rmin[3]; int32_t pad0;
-    float rmax[3]; int32_t pad1;
+    float origin[3]; float step_x;
+    int32_t child[4];
+    uint32_t qlo[3]; uint32_t qhi_x;
+    uint32_t qhi_y, qhi_z; float step_y, step_z;
 } flat_node_t;
 typedef struct {
     float p0[3]; int32_t rank;
@@ -403,15 +403,15 @@ typedef struct {
 } flat_tri_t;
 
 #define FLAT_PAD 1.0000002384185791015625f
+#define FLAT_EMPTY_CHILD INT32_MIN
 
-static inline int flat_slab(const float* bmin, const float* bmax, v3 o, v3 inv, float min_t, float best_t, float* entry) {
-    v3 fv = mul3(sub3(V3(bmax[0], bmax[1], bmax[2]), o), inv);
-    v3 nv = mul3(sub3(V3(bmin[0], bmin[1], bmin[2]), o), inv);
-    float t1 = fmin_(fmin_(fmax_(fv.x, nv.x), fmin_(fmax_(fv.y, nv.y), fmax_(fv.z, nv.z))), best_t);
-    float t0 = fmax_(fmax_(fmax_(fmin_(fv.x, nv.x), fmax_(fmin_(fv.y, nv.y), fmin_(fv.z, nv.z))), min_t), 0.0f);
-    *entry = t0;
-    return t1 * FLAT_PAD >= t0;
-}
+/* 4-wide node.  Per node and axis: A = step * (1/d), B = (origin - o) * (1/d); the distance to the child
+ * plane with quantised offset q is t = fma(q, A, B).  The sign of 1/d selects which of a child's two planes
+ * is the entry and which the exit.  NaN distances (0 * inf) are ignored by max/min = "no constraint".
+ * Entry = max(entry planes, min_t), exit = min(exit planes, best_t), hit iff exit * (1 + 2^-22) >= entry.
+ * The host pads the quantised boxes by 2^-20 of the node extent, which covers the rounding of A, B and the fma. */
+static inline float max3_(float a, float b, float c) { return fmax_(fmax_(a, b), c); }
+static inline float min3_(float a, float b, float c) { return fmin_(fmin_(a, b), c); }
 
 int orc_closest_hit_flat(const void* blob, const float origin[3], const float dir[3], float min_t, float max_t,
                          int32_t* prim_out, float* t_out, float bary_out[3], orc_counters* c) {
@@ -420,27 +420,54 @@ int orc_closest_hit_flat(const void* blob, const float origin[3], const float di
     const flat_tri_t* tris = (const flat_tri_t*)((const uint8_t*)blob + h->triangles_offset);
     v3 o = V3(origin[0], origin[1], origin[2]), d = V3(dir[0], dir[1], dir[2]);
     v3 inv = V3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    const int neg_x = is_neg(inv.x), neg_y = is_neg(inv.y), neg_z = is_neg(inv.z);
     float best_t = max_t, best_u = 0, best_v = 0;
     int32_t best_rank = -1, best_prim = -1;
     int hit = 0;
-    int32_t stack[128];
+    int32_t stack[256];
     int sp = 0;
     int32_t cur = h->root;
     uint64_t n_nodes = 0, n_tris = 0;
+    const float inf = INFINITY;
     for (;;) {
         if (cur >= 0) {
             const flat_node_t* nd = &nodes[cur];
             n_nodes++;
-            float el, er;
-            int hl = flat_slab(nd->lmin, nd->lmax, o, inv, min_t, best_t, &el);
-            int hr = flat_slab(nd->rmin, nd->rmax, o, inv, min_t, best_t, &er);
-            if (hl && hr) {
-                if (er < el) { stack[sp++] = nd->left; cur = nd->right; }
-                else { stack[sp++] = nd->right; cur = nd->left; }
+            const float Ax = nd->step_x * inv.x, Ay = nd->step_y * inv.y, Az = nd->step_z * inv.z;
+            const float Bx = (nd->origin[0] - o.x) * inv.x, By = (nd->origin[1] - o.y) * inv.y, Bz = (nd->origin[2] - o.z) * inv.z;
+            const uint32_t near_x = neg_x ? nd->qhi_x : nd->qlo[0], far_x = neg_x ? nd->qlo[0] : nd->qhi_x;
+            const uint32_t near_y = neg_y ? nd->qhi_y : nd->qlo[1], far_y = neg_y ? nd->qlo[1] : nd->qhi_y;
+            const uint32_t near_z = neg_z ? nd->qhi_z : nd->qlo[2], far_z = neg_z ? nd->qlo[2] : nd->qhi_z;
+            float key[4];
+            int32_t ref[4];
+            for (int k = 0; k < 4; k++) {
+                ref[k] = nd->child[k];
+                key[k] = inf;
+                if (ref[k] == FLAT_EMPTY_CHILD) continue;
+                const int sh = 8 * k;
+                const float nx = fmaf((float)((near_x >> sh) & 0xffu), Ax, Bx), fx = fmaf((float)((far_x >> sh) & 0xffu), Ax, Bx);
+                const float ny = fmaf((float)((near_y >> sh) & 0xffu), Ay, By), fy = fmaf((float)((far_y >> sh) & 0xffu), Ay, By);
+                const float nz = fmaf((float)((near_z >> sh) & 0xffu), Az, Bz), fz = fmaf((float)((far_z >> sh) & 0xffu), Az, Bz);
+                const float t0 = fmax_(max3_(nx, ny, nz), min_t);
+                const float t1 = fmin_(min3_(fx, fy, fz), best_t);
+                if (t1 * FLAT_PAD >= t0) key[k] = t0;
+            }
+            /* sorting network (0,1)(2,3)(0,2)(1,3)(1,2): nearest entry first; misses (+inf) sink to the end */
+            static const int net[5][2] = { { 0, 1 }, { 2, 3 }, { 0, 2 }, { 1, 3 }, { 1, 2 } };
+            for (int s = 0; s < 5; s++) {
+                const int a = net[s][0], b = net[s][1];
+                if (key[a] > key[b]) {
+                    float tk = key[a]; key[a] = key[b]; key[b] = tk;
+                    int32_t tr = ref[a]; ref[a] = ref[b]; ref[b] = tr;
+                }
+            }
+            int n = 0;
+            for (int k = 0; k < 4; k++) n += key[k] < inf;
+            if (n > 0) {
+                for (int k = n - 1; k >= 1; k--) stack[sp++] = ref[k];  /* farthest first, so the nearer pops first */
+                cur = ref[0];
                 continue;
             }
-            if (hl) { cur = nd->left; continue; }
-            if (hr) { cur = nd->right; continue; }
         } else {
             uint32_t ref = (uint32_t)~cur;
             uint32_t first = ref >> 2, count = (ref & 3u) + 1u;

@@ -66,9 +66,11 @@ struct ptr_ctx {
     ptr::WavefrontScratch scratch{};
     void* scratch_block = nullptr;
     int cu_count = 256;
+    int opt_extend_inner_reps = 2;  // inner-node steps per inner turn
+    int opt_extend_leaf_all = 1;    // 1: a leaf turn tests every triangle of the leaf, 0: one triangle per turn
     int opt_extend_leaf_weight = 2; // leaf lanes count this many times when a traversal wave picks its next step kind
     int opt_extend_refill = 16;     // idle lanes that trigger a refill of the traversal wave (8, 16, 32, 48, 64)
-    int opt_extend_blocks_per_cu = 4;
+    int opt_extend_blocks_per_cu = 8;
     // small host->device writes (the per-frame 160-byte metadata) go through a ring of pinned slots so that
     // Buffer::write returns without draining the stream
     static constexpr int kStageSlots = 32;
@@ -288,7 +290,7 @@ int dispatch_compute(ptr_ctx* c, const uint8_t constants[64], uint32_t gx, uint3
         if (flat_buf->size < sizeof hd) return fail(c, PTR_E_STATE, "flattened layout: blob shorter than its header");
         PTR_HIP_CHECK(c, hipMemcpyAsync(&hd, flat_buf->ptr, sizeof hd, hipMemcpyDeviceToHost, c->stream));
         PTR_HIP_CHECK(c, hipStreamSynchronize(c->stream));
-        if (hd.magic != 0x46525450u || hd.version != 1u) return fail(c, PTR_E_STATE, "flattened layout: bad magic/version");
+        if (hd.magic != 0x46525450u || hd.version != 2u) return fail(c, PTR_E_STATE, "flattened layout: bad magic/version");
         if ((hd.nodes_offset & 63u) || (hd.triangles_offset & 63u)) return fail(c, PTR_E_STATE, "flattened layout: sections are not 64-byte aligned");
         if (hd.nodes_offset + (uint64_t)hd.node_count * 64 > flat_buf->size || hd.triangles_offset + (uint64_t)hd.triangle_count * 64 > flat_buf->size)
             return fail(c, PTR_E_STATE, "flattened layout: sections exceed the buffer");
@@ -320,7 +322,7 @@ int dispatch_compute(ptr_ctx* c, const uint8_t constants[64], uint32_t gx, uint3
             PTR_HIP_CHECK(c, hipMemsetAsync(w.counters + s, 0, 4, c->stream));
             PTR_HIP_CHECK(c, hipMemsetAsync(w.counters + ptr::kMaxBounceSlots + s, 0, 4, c->stream));
         }
-        { ScopedProfile prof(c, "wavefront.extend"); PTR_HIP_CHECK(c, ptr::launch_wf_extend(c->stream, fv, w, b, sv.stats, c->opt_extend_refill, c->opt_extend_leaf_weight)); }
+        { ScopedProfile prof(c, "wavefront.extend"); PTR_HIP_CHECK(c, ptr::launch_wf_extend(c->stream, fv, w, b, sv.stats, c->opt_extend_refill, c->opt_extend_leaf_weight, c->opt_extend_leaf_all, c->opt_extend_inner_reps)); }
         { ScopedProfile prof(c, "wavefront.shade"); PTR_HIP_CHECK(c, ptr::launch_wf_shade(c->stream, sv, w, b, meta.max_bounce, meta.min_bounce, domain_w, domain_h)); }
     }
     { ScopedProfile prof(c, "wavefront.accumulate"); PTR_HIP_CHECK(c, ptr::launch_wf_accumulate(c->stream, sv, w, domain_w, domain_h)); }
@@ -631,12 +633,22 @@ int ptr_set_option(ptr_ctx* c, const char* key, int value) {
         return PTR_OK;
     }
     if (!strcmp(key, "extend.leaf_weight")) {
-        if (value != 1 && value != 2 && value != 4 && value != 8) return fail(c, PTR_E_INVALID, "extend.leaf_weight: 1, 2, 4 or 8");
+        if (value != 1 && value != 2 && value != 4) return fail(c, PTR_E_INVALID, "extend.leaf_weight: 1, 2 or 4");
         c->opt_extend_leaf_weight = value;
         return PTR_OK;
     }
+    if (!strcmp(key, "extend.inner_reps")) {
+        if (value < 1 || value > 3) return fail(c, PTR_E_INVALID, "extend.inner_reps: 1..3");
+        c->opt_extend_inner_reps = value;
+        return PTR_OK;
+    }
+    if (!strcmp(key, "extend.leaf_all")) {
+        if (value != 0 && value != 1) return fail(c, PTR_E_INVALID, "extend.leaf_all: 0 or 1");
+        c->opt_extend_leaf_all = value;
+        return PTR_OK;
+    }
     if (!strcmp(key, "extend.blocks_per_cu")) {
-        if (value < 1 || value > 6) return fail(c, PTR_E_INVALID, "extend.blocks_per_cu: 1..6 (24 KiB of LDS per block)");
+        if (value < 1 || value > 8) return fail(c, PTR_E_INVALID, "extend.blocks_per_cu: 1..8");
         c->opt_extend_blocks_per_cu = value;
         return PTR_OK;
     }

@@ -34,8 +34,8 @@ struct WavefrontScratch {
 
 constexpr uint32_t kMaxBounceSlots = 16;   // counters per array; deeper paths reuse the slots cyclically
 constexpr uint32_t kExtendThreads = 256;
-constexpr uint32_t kStackLds = 24;         // per-lane traversal stack entries kept in LDS
-constexpr uint32_t kStackSpill = 40;       // further entries in global memory (64 total >= FLAT_BVH_MAX_DEPTH)
+constexpr uint32_t kStackLds = 16;         // per-lane traversal stack entries kept in LDS
+constexpr uint32_t kStackSpill = 48;       // further entries in global memory (64 total >= FLAT_BVH_MAX_DEPTH)
 
 // compute.comp as one kernel over the threaded node array (one wave = one 8x8 workgroup).
 hipError_t launch_megakernel(hipStream_t s, const SceneView& sv, uint32_t groups_x, uint32_t groups_y, bool stats);
@@ -50,7 +50,7 @@ hipError_t launch_linearize_resolve(hipStream_t s, const ImageDesc* images, uint
 // Wavefront stages.  domain_w/h = pixels of the dispatch that exist (min(groups*8, width/height)).
 hipError_t launch_wf_generate(hipStream_t s, const SceneView& sv, const WavefrontScratch& w, uint32_t domain_w, uint32_t domain_h);
 hipError_t launch_wf_extend(hipStream_t s, const FlatView& fv, const WavefrontScratch& w, uint32_t bounce, unsigned long long* stats,
-                            int refill, int leaf_weight);
+                            int refill, int leaf_weight, int leaf_all, int inner_reps);
 hipError_t launch_wf_shade(hipStream_t s, const SceneView& sv, const WavefrontScratch& w, uint32_t bounce, uint32_t max_bounce,
                            uint32_t min_bounce, uint32_t domain_w, uint32_t domain_h);
 hipError_t launch_wf_accumulate(hipStream_t s, const SceneView& sv, const WavefrontScratch& w, uint32_t domain_w, uint32_t domain_h);

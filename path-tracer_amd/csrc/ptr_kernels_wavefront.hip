@@ -1,9 +1,8 @@
 // "compute" as a wavefront pipeline over the flattened BVH layout:
 //
 //   generate   one lane per pixel: RNG seed + thin-lens camera ray -> ray/state queues (SoA)
-//   extend     persistent wave64 traversal: waves pull 64 rays at a time from the queue with one
-//              atomic, walk the 64-byte two-child nodes near-child-first with a per-lane stack in LDS
-//              (overflow in global memory), test the 64-byte pre-gathered triangle records
+//   extend     persistent wave64 traversal of the 4-wide, 8-bit-quantised 64-byte nodes, nearest child
+//              first, per-lane stack in LDS (overflow in global memory), 64-byte pre-gathered triangles
 //   shade      one lane per live path: material fetch, BRDF sampling, Russian roulette; survivors are
 //              compacted into the next generation's queues (ballot + one atomic per wave)
 //   accumulate one lane per pixel: temporal mean with the accumulation image -> output image
@@ -58,17 +57,39 @@ __global__ __launch_bounds__(256) void ptr_wf_generate(SceneView sv, WavefrontSc
 }
 
 // ---- extend --------------------------------------------------------------------------------------------
-struct SlabResult { bool hit; float entry; };
+constexpr int32_t kEmptyChild = INT32_MIN;
 
-PTR_DEV SlabResult slab(const float4 lo, const float4 hi, const f3 o, const f3 inv, float min_t, float best_t) {
-    const f3 fv = (mk3(hi.x, hi.y, hi.z) - o) * inv;
-    const f3 nv = (mk3(lo.x, lo.y, lo.z) - o) * inv;
-    const float t1 = min_num(min_num(max_num(fv.x, nv.x), min_num(max_num(fv.y, nv.y), max_num(fv.z, nv.z))), best_t);
-    const float t0 = max_num(max_num(max_num(min_num(fv.x, nv.x), max_num(min_num(fv.y, nv.y), min_num(fv.z, nv.z))), min_t), 0.0f);
-    SlabResult s;
-    s.entry = t0;
-    s.hit = t1 * kBoxPad >= t0;
-    return s;
+// Entry distance of one child box of a 4-wide node, or +inf when the ray misses it.
+// Per node and axis the caller folds the ray into A = step / d and B = (origin - o) / d, so the distance to the
+// plane at quantised offset q is ONE fused multiply-add, t = fma(q, A, B); the sign of 1/d has already picked
+// which byte is the entry plane and which the exit plane.  v_max3 / v_min3 ignore NaN distances (0 * inf).
+// The host pads the quantised boxes by 2^-20 of the node extent, which covers the rounding of A, B and the fma;
+// the (1 + 2^-22) factor covers the part of the error that is relative to t.
+PTR_DEV float child_entry(uint32_t nx, uint32_t ny, uint32_t nz, uint32_t fx, uint32_t fy, uint32_t fz, const f3 A, const f3 B, float min_t,
+                          float best_t) {
+    const float tnx = __builtin_fmaf((float)nx, A.x, B.x), tfx = __builtin_fmaf((float)fx, A.x, B.x);
+    const float tny = __builtin_fmaf((float)ny, A.y, B.y), tfy = __builtin_fmaf((float)fy, A.y, B.y);
+    const float tnz = __builtin_fmaf((float)nz, A.z, B.z), tfz = __builtin_fmaf((float)fz, A.z, B.z);
+    const float t0 = max_num(max_num(max_num(tnx, tny), tnz), min_t);
+    const float t1 = min_num(min_num(min_num(tfx, tfy), tfz), best_t);
+    return (t1 * kBoxPad >= t0) ? t0 : __builtin_inff();
+}
+
+// compare-exchange of (key, reference) pairs, select form (no divergent branch)
+PTR_DEV void sort_pair(float& ka, int32_t& ra, float& kb, int32_t& rb) {
+    const bool swap = ka > kb;
+    const float k_lo = swap ? kb : ka, k_hi = swap ? ka : kb;
+    const int32_t r_lo = swap ? rb : ra, r_hi = swap ? ra : rb;
+    ka = k_lo; kb = k_hi; ra = r_lo; rb = r_hi;
+}
+
+// Pop of the per-lane traversal stack: entry `sp` lives in LDS when sp < kStackLds (the common case: one
+// ds_read), deeper entries in the global spill area (rare, separate branch so that the compiler keeps the two
+// address spaces apart instead of falling back to a flat load).
+PTR_DEV int32_t stack_pop(const int32_t* lds, const int32_t* spill, uint32_t sp) {
+    int32_t v = lds[(sp < kStackLds ? sp : 0u) * 64u];
+    if (sp >= kStackLds) v = spill[(sp - kStackLds) * 64u];
+    return v;
 }
 
 constexpr int32_t kTraversalDone = INT32_MIN;  // never a leaf reference: triangle counts stay below 2^29
@@ -86,7 +107,7 @@ constexpr int32_t kTraversalDone = INT32_MIN;  // never a leaf reference: triang
 //     leaf hit shortens the ray and culls later nodes); the other lanes keep their state and wait.  A ray's own
 //     sequence of steps never changes, only when it is executed.
 //   * Per-lane stack: kStackLds entries in LDS (lane-interleaved, conflict-free), deeper entries in global memory.
-template <bool STATS, int REFILL, int LEAF_WEIGHT>
+template <bool STATS, int REFILL, int LEAF_WEIGHT, bool LEAF_ALL, int INNER_REPS>
 __global__ __launch_bounds__(kExtendThreads, 4) void ptr_wf_extend(FlatView fv, WavefrontScratch w, uint32_t gen, uint32_t slot_b,
                                                                 unsigned long long* stats) {
     __shared__ int32_t lds_stack[(kExtendThreads / 64) * kStackLds * 64];
@@ -108,6 +129,7 @@ __global__ __launch_bounds__(kExtendThreads, 4) void ptr_wf_extend(FlatView fv, 
     const float min_t = 0.001f;
     uint32_t slot = kInvalidPixel;              // queue slot this lane is tracing; kInvalidPixel = idle
     f3 o = mk3(0, 0, 0), d = mk3(0, 0, 1), inv = mk3(0, 0, 1);
+    bool neg_x = false, neg_y = false, neg_z = false;  // sign bits of 1/d: which plane of a slab is the entry
     float best_t = 1e15f, best_u = 0.0f, best_v = 0.0f;
     int32_t best_rank = -1, best_prim = -1;
     int32_t cur = kTraversalDone;
@@ -125,6 +147,7 @@ __global__ __launch_bounds__(kExtendThreads, 4) void ptr_wf_extend(FlatView fv, 
                         o = mk3(w.ray[gen][0][idx], w.ray[gen][1][idx], w.ray[gen][2][idx]);
                         d = mk3(w.ray[gen][3][idx], w.ray[gen][4][idx], w.ray[gen][5][idx]);
                         inv = mk3(rcp(d.x), rcp(d.y), rcp(d.z));
+                        neg_x = (as_u32(inv.x) >> 31) != 0u; neg_y = (as_u32(inv.y) >> 31) != 0u; neg_z = (as_u32(inv.z) >> 31) != 0u;
                         best_t = 1e15f; best_u = 0.0f; best_v = 0.0f; best_rank = -1; best_prim = -1;
                         cur = fv.root; sp = 0u;
                         if (STATS) n_rays++;
@@ -141,39 +164,67 @@ __global__ __launch_bounds__(kExtendThreads, 4) void ptr_wf_extend(FlatView fv, 
         const uint32_t n_inner = (uint32_t)__popcll(__ballot(at_inner));
         const uint32_t n_leaf = (uint32_t)__popcll(__ballot(at_leaf));
         const bool leaf_turn = n_leaf * (uint32_t)LEAF_WEIGHT > n_inner;
-        if (STATS) { if (leaf_turn) wave_leaf_steps++; else wave_inner_steps++; }
+        if (STATS) { if (leaf_turn) wave_leaf_steps++; else wave_inner_steps += INNER_REPS; }
 
-        if (!leaf_turn && at_inner) {  // one inner-node step
-            const float4 q0 = fv.nodes[4 * cur], q1 = fv.nodes[4 * cur + 1];
-            const float4 q2 = fv.nodes[4 * cur + 2], q3 = fv.nodes[4 * cur + 3];
+        // kInnerReps 4-wide nodes per inner turn (four box tests each, nearest child next, the others stacked):
+        // repeating the step amortises the per-iteration bookkeeping (ballots, refill test, completion)
+        #pragma unroll 1
+        for (int rep = 0; rep < INNER_REPS; rep++)
+        if (!leaf_turn && slot != kInvalidPixel && cur >= 0) {
+            const float4 q0 = fv.nodes[4 * cur];                      // origin.xyz, step.x
+            const int4 refs = ((const int4*)fv.nodes)[4 * cur + 1];
+            const uint4 qa = ((const uint4*)fv.nodes)[4 * cur + 2];  // lo.x lo.y lo.z hi.x
+            const uint4 qb = ((const uint4*)fv.nodes)[4 * cur + 3];  // hi.y hi.z step.y step.z
             if (STATS) n_nodes++;
-            const SlabResult l = slab(q0, q1, o, inv, min_t, best_t);
-            const SlabResult r = slab(q2, q3, o, inv, min_t, best_t);
-            const int32_t left = __float_as_int(q0.w), right = __float_as_int(q1.w);
-            if (l.hit && r.hit) {
-                const bool right_first = r.entry < l.entry;
-                const int32_t far_ref = right_first ? left : right;
-                if (sp < kStackLds) my_lds[sp * 64u] = far_ref;
-                else my_spill[(sp - kStackLds) * 64u] = far_ref;
-                sp++;
-                cur = right_first ? right : left;
-            } else if (l.hit) {
-                cur = left;
-            } else if (r.hit) {
-                cur = right;
+            const f3 A = mk3(q0.w * inv.x, __uint_as_float(qb.z) * inv.y, __uint_as_float(qb.w) * inv.z);
+            const f3 B = mk3((q0.x - o.x) * inv.x, (q0.y - o.y) * inv.y, (q0.z - o.z) * inv.z);
+            const uint32_t near_x = neg_x ? qa.w : qa.x, far_x = neg_x ? qa.x : qa.w;
+            const uint32_t near_y = neg_y ? qb.x : qa.y, far_y = neg_y ? qa.y : qb.x;
+            const uint32_t near_z = neg_z ? qb.y : qa.z, far_z = neg_z ? qa.z : qb.y;
+            int32_t r0 = refs.x, r1 = refs.y, r2 = refs.z, r3 = refs.w;
+            const float inf = __builtin_inff();
+            float k0 = child_entry(near_x & 0xffu, near_y & 0xffu, near_z & 0xffu, far_x & 0xffu, far_y & 0xffu, far_z & 0xffu, A, B, min_t, best_t);
+            float k1 = child_entry((near_x >> 8) & 0xffu, (near_y >> 8) & 0xffu, (near_z >> 8) & 0xffu, (far_x >> 8) & 0xffu, (far_y >> 8) & 0xffu,
+                                   (far_z >> 8) & 0xffu, A, B, min_t, best_t);
+            float k2 = child_entry((near_x >> 16) & 0xffu, (near_y >> 16) & 0xffu, (near_z >> 16) & 0xffu, (far_x >> 16) & 0xffu,
+                                   (far_y >> 16) & 0xffu, (far_z >> 16) & 0xffu, A, B, min_t, best_t);
+            float k3 = child_entry(near_x >> 24, near_y >> 24, near_z >> 24, far_x >> 24, far_y >> 24, far_z >> 24, A, B, min_t, best_t);
+            if (r2 == kEmptyChild) k2 = inf;  // children fill the slots from the front; 0 and 1 always exist
+            if (r3 == kEmptyChild) k3 = inf;
+            sort_pair(k0, r0, k1, r1);
+            sort_pair(k2, r2, k3, r3);
+            sort_pair(k0, r0, k2, r2);
+            sort_pair(k1, r1, k3, r3);
+            sort_pair(k1, r1, k2, r2);
+            if (k0 < inf) {
+                // stack the farther hits farthest-first so that the nearer one pops first
+                if (sp + 3u <= kStackLds) {
+                    // common case, branch-free: hits are sorted to the front, so writing r3, r2, r1 at advancing
+                    // positions leaves exactly the hit ones below the new top (a miss is overwritten or left above it)
+                    my_lds[sp * 64u] = r3; sp += (k3 < inf) ? 1u : 0u;
+                    my_lds[sp * 64u] = r2; sp += (k2 < inf) ? 1u : 0u;
+                    my_lds[sp * 64u] = r1; sp += (k1 < inf) ? 1u : 0u;
+                } else {
+                    if (k3 < inf) { if (sp < kStackLds) my_lds[sp * 64u] = r3; else my_spill[(sp - kStackLds) * 64u] = r3; sp++; }
+                    if (k2 < inf) { if (sp < kStackLds) my_lds[sp * 64u] = r2; else my_spill[(sp - kStackLds) * 64u] = r2; sp++; }
+                    if (k1 < inf) { if (sp < kStackLds) my_lds[sp * 64u] = r1; else my_spill[(sp - kStackLds) * 64u] = r1; sp++; }
+                }
+                cur = r0;
             } else if (sp == 0u) {
                 cur = kTraversalDone;
             } else {
                 sp--;
-                cur = sp < kStackLds ? my_lds[sp * 64u] : my_spill[(sp - kStackLds) * 64u];
+                cur = stack_pop(my_lds, my_spill, sp);
             }
         }
 
-        if (leaf_turn && at_leaf) {  // all triangles of one leaf
-            const uint32_t ref = (uint32_t)~cur;
-            const uint32_t first = ref >> 2, tri_count = (ref & 3u) + 1u;
-            for (uint32_t k = 0; k < tri_count; k++) {
-                const float4* tr = fv.triangles + 4 * (size_t)(first + k);
+        if (leaf_turn && at_leaf) {
+            // LEAF_ALL: every triangle of the lane's leaf in this turn; otherwise ONE triangle, the rest of the leaf
+            // stays encoded in `cur` for the next leaf turn (lanes with short leaves get back to inner nodes sooner)
+            uint32_t ref = (uint32_t)~cur;
+            for (;;) {
+                const uint32_t first = ref >> 2, remaining = ref & 3u;  // triangles left after this one
+                const float4* tr = fv.triangles + 4 * (size_t)first;
                 const float4 a = tr[0], b = tr[1], c = tr[2], n4 = tr[3];
                 if (STATS) n_tris++;
                 const f3 e1 = mk3(b.x, b.y, b.z), e2 = mk3(c.x, c.y, c.z), n = mk3(n4.x, n4.y, n4.z);
@@ -183,17 +234,22 @@ __global__ __launch_bounds__(kExtendThreads, 4) void ptr_wf_extend(FlatView fv, 
                 const float u = dd * dot(-q, e2);
                 const float v = dd * dot(q, e1);
                 const float t = dd * dot(-n, ov);
-                if (u < 0.0f || u > 1.0f || v < 0.0f || u + v > 1.0f || t < min_t || t > best_t) continue;
-                if (t != t || u != u || v != v) continue;
+                const bool reject = u < 0.0f || u > 1.0f || v < 0.0f || u + v > 1.0f || t < min_t || t > best_t || t != t || u != u || v != v;
                 const int32_t rank = __float_as_int(a.w);
-                if (best_prim >= 0 && t == best_t && rank < best_rank) continue;
-                best_t = t; best_u = u; best_v = v; best_rank = rank; best_prim = __float_as_int(b.w);
+                if (!reject && !(best_prim >= 0 && t == best_t && rank < best_rank)) {
+                    best_t = t; best_u = u; best_v = v; best_rank = rank; best_prim = __float_as_int(b.w);
+                }
+                if (remaining == 0u) { ref = 0xffffffffu; break; }
+                ref = ((first + 1u) << 2) | (remaining - 1u);
+                if (!LEAF_ALL) break;
             }
-            if (sp == 0u) {
+            if (ref != 0xffffffffu) {
+                cur = ~(int32_t)ref;
+            } else if (sp == 0u) {
                 cur = kTraversalDone;
             } else {
                 sp--;
-                cur = sp < kStackLds ? my_lds[sp * 64u] : my_spill[(sp - kStackLds) * 64u];
+                cur = stack_pop(my_lds, my_spill, sp);
             }
         }
 
@@ -319,30 +375,39 @@ hipError_t launch_wf_generate(hipStream_t s, const SceneView& sv, const Wavefron
     return hipGetLastError();
 }
 
-template <bool STATS, int LEAF_WEIGHT>
+template <bool STATS, int LEAF_WEIGHT, bool LEAF_ALL, int INNER_REPS>
 static void launch_extend_variant(hipStream_t s, const FlatView& fv, const WavefrontScratch& w, uint32_t bounce, unsigned long long* stats,
                                   int refill) {
     const uint32_t slot_b = bounce % kMaxBounceSlots;
     const dim3 grid(w.extend_blocks), block(kExtendThreads);
     switch (refill) {
-    case 8: hipLaunchKernelGGL((ptr_wf_extend<STATS, 8, LEAF_WEIGHT>), grid, block, 0, s, fv, w, bounce & 1u, slot_b, stats); break;
-    case 16: hipLaunchKernelGGL((ptr_wf_extend<STATS, 16, LEAF_WEIGHT>), grid, block, 0, s, fv, w, bounce & 1u, slot_b, stats); break;
-    case 32: hipLaunchKernelGGL((ptr_wf_extend<STATS, 32, LEAF_WEIGHT>), grid, block, 0, s, fv, w, bounce & 1u, slot_b, stats); break;
-    default: hipLaunchKernelGGL((ptr_wf_extend<STATS, 64, LEAF_WEIGHT>), grid, block, 0, s, fv, w, bounce & 1u, slot_b, stats); break;
+    case 8: hipLaunchKernelGGL((ptr_wf_extend<STATS, 8, LEAF_WEIGHT, LEAF_ALL, INNER_REPS>), grid, block, 0, s, fv, w, bounce & 1u, slot_b, stats); break;
+    case 16: hipLaunchKernelGGL((ptr_wf_extend<STATS, 16, LEAF_WEIGHT, LEAF_ALL, INNER_REPS>), grid, block, 0, s, fv, w, bounce & 1u, slot_b, stats); break;
+    case 32: hipLaunchKernelGGL((ptr_wf_extend<STATS, 32, LEAF_WEIGHT, LEAF_ALL, INNER_REPS>), grid, block, 0, s, fv, w, bounce & 1u, slot_b, stats); break;
+    default: hipLaunchKernelGGL((ptr_wf_extend<STATS, 64, LEAF_WEIGHT, LEAF_ALL, INNER_REPS>), grid, block, 0, s, fv, w, bounce & 1u, slot_b, stats); break;
     }
 }
 
 hipError_t launch_wf_extend(hipStream_t s, const FlatView& fv, const WavefrontScratch& w, uint32_t bounce, unsigned long long* stats,
-                            int refill, int leaf_weight) {
+                            int refill, int leaf_weight, int leaf_all, int inner_reps) {
     if (stats) {
-        launch_extend_variant<true, 2>(s, fv, w, bounce, stats, refill);
-    } else {
+        launch_extend_variant<true, 2, true, 1>(s, fv, w, bounce, stats, refill);
+    } else if (!leaf_all) {
+        launch_extend_variant<false, 2, false, 1>(s, fv, w, bounce, stats, refill);
+    } else if (inner_reps == 1) {
         switch (leaf_weight) {
-        case 1: launch_extend_variant<false, 1>(s, fv, w, bounce, stats, refill); break;
-        case 4: launch_extend_variant<false, 4>(s, fv, w, bounce, stats, refill); break;
-        case 8: launch_extend_variant<false, 8>(s, fv, w, bounce, stats, refill); break;
-        default: launch_extend_variant<false, 2>(s, fv, w, bounce, stats, refill); break;
+        case 1: launch_extend_variant<false, 1, true, 1>(s, fv, w, bounce, stats, refill); break;
+        case 4: launch_extend_variant<false, 4, true, 1>(s, fv, w, bounce, stats, refill); break;
+        default: launch_extend_variant<false, 2, true, 1>(s, fv, w, bounce, stats, refill); break;
         }
+    } else if (inner_reps == 2) {
+        switch (leaf_weight) {
+        case 1: launch_extend_variant<false, 1, true, 2>(s, fv, w, bounce, stats, refill); break;
+        case 4: launch_extend_variant<false, 4, true, 2>(s, fv, w, bounce, stats, refill); break;
+        default: launch_extend_variant<false, 2, true, 2>(s, fv, w, bounce, stats, refill); break;
+        }
+    } else {
+        launch_extend_variant<false, 2, true, 3>(s, fv, w, bounce, stats, refill);
     }
     return hipGetLastError();
 }

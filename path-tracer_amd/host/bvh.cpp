@@ -2,6 +2,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <cmath>
 #include <cstring>
 #include <iostream>
 #include <thread>
@@ -436,6 +437,67 @@ std::vector<int32_t> bvh::visit_ranks(const std::vector<packed_bvh_node>& packed
     return ranks;
 }
 
+namespace {
+
+// ---- 4-wide collapse + 8-bit quantisation of the SAH tree ----------------------------------------------
+struct wide_node {
+    int32_t child[4];   // indices into the sah_node vector
+    uint32_t count = 0;
+};
+
+// 2^(biased - 127) as a float, the per-axis quantisation step of a node
+float scale_from_biased(uint32_t biased) {
+    const uint32_t bits = biased << 23;
+    float f;
+    std::memcpy(&f, &bits, 4);
+    return f;
+}
+
+// Decoded bound exactly as the kernels compute it: origin + q * step (the product is exact: q <= 255 and step
+// is a power of two, so a fused multiply-add and a multiply followed by an add give the same bits).
+float dequantise(float origin, uint32_t q, float step) { return origin + (float)q * step; }
+
+// Chooses the origin and step of one axis and quantises the children's [lo, hi] with a safety margin:
+//     decoded lo <= true lo - margin   and   decoded hi >= true hi + margin,   margin = 2^-20 * node extent.
+// The margin is what makes the kernels' folded slab arithmetic (t = fma(q, step/d, (origin - o)/d)) conservative:
+// its absolute rounding error is a few 2^-24 of the node extent when the ray starts near the node, and relative
+// to t (covered by the pad on the exit distance) when it starts far away.
+void quantise_axis(float node_lo, float node_hi, const float* lo, const float* hi, uint32_t count, float& origin, uint32_t& biased,
+                   uint8_t* qlo, uint8_t* qhi) {
+    const float extent = node_hi - node_lo;
+    const float margin = std::max(extent * 9.5367431640625e-07f, 1e-30f);  // 2^-20 * extent
+    origin = std::nextafter(node_lo - margin, -std::numeric_limits<float>::infinity());
+    const float span = (node_hi + margin) - origin;
+    int e = -126;
+    {
+        int ex;
+        std::frexp((double)span / 255.0, &ex);  // span/255 = m * 2^ex, m in [0.5, 1)  ->  2^ex >= span/255
+        e = std::max(-126, std::min(127, ex));
+    }
+    for (;; e++) {
+        if (e > 127) throw bvh_build_error("flatten: node extent cannot be quantised");
+        const float step = scale_from_biased((uint32_t)(e + 127));
+        bool ok = true;
+        for (uint32_t k = 0; k < count && ok; k++) {
+            const float want_lo = lo[k] - margin, want_hi = hi[k] + margin;
+            double ql = std::floor(((double)want_lo - (double)origin) / (double)step);
+            ql = std::max(0.0, std::min(255.0, ql));
+            uint32_t a = (uint32_t)ql;
+            while (a > 0 && dequantise(origin, a, step) > want_lo) a--;
+            double qh = std::ceil(((double)want_hi - (double)origin) / (double)step);
+            qh = std::max(0.0, std::min(255.0, qh));
+            uint32_t b = (uint32_t)qh;
+            while (b < 255 && dequantise(origin, b, step) < want_hi) b++;
+            if (dequantise(origin, a, step) > want_lo || dequantise(origin, b, step) < want_hi) { ok = false; break; }
+            qlo[k] = (uint8_t)a;
+            qhi[k] = (uint8_t)b;
+        }
+        if (ok) { biased = (uint32_t)(e + 127); return; }
+    }
+}
+
+}  // namespace
+
 std::vector<uint8_t> bvh::flatten(const std::vector<triangle>& tris, const std::vector<int32_t>& ranks, unsigned threads) {
     if (tris.empty()) throw bvh_build_error("flatten: no triangles");
     if (tris.size() >= (1u << 29)) throw bvh_build_error("flatten: too many triangles for the leaf reference encoding");
@@ -444,31 +506,60 @@ std::vector<uint8_t> bvh::flatten(const std::vector<triangle>& tris, const std::
     std::vector<int32_t> order;
     const std::vector<sah_node> nodes = build_sah(tris, order, 4, threads);
 
-    // Inner nodes get their flat index in depth-first pre-order (a node's left subtree follows it).
-    std::vector<int32_t> flat_index(nodes.size(), -1);
+    // Collapse to 4 children per node: starting from a node's two children, the inner child with the largest
+    // surface area is replaced by its own two children until there are four (or only leaves are left).
+    auto collapse = [&](uint32_t id) {
+        wide_node w;
+        w.child[0] = nodes[id].left; w.child[1] = nodes[id].right; w.count = 2;
+        while (w.count < 4) {
+            int best = -1;
+            float best_area = -1.f;
+            for (uint32_t k = 0; k < w.count; k++) {
+                const sah_node& c = nodes[w.child[k]];
+                if (c.left < 0) continue;
+                const float a = c.box.surface_area();
+                if (a > best_area) { best_area = a; best = (int)k; }
+            }
+            if (best < 0) break;
+            const sah_node& c = nodes[w.child[best]];
+            w.child[best] = c.left;           // keep the near-origin order stable: left in place, right appended
+            w.child[w.count++] = c.right;
+        }
+        return w;
+    };
+
+    // Pass 1 (depth-first pre-order): number the wide nodes, place the triangles in leaf order, bound the stack.
+    std::vector<int32_t> wide_index(nodes.size(), -1);
     std::vector<uint32_t> leaf_first(nodes.size(), 0);
-    uint32_t inner_count = 0, tri_cursor = 0, max_depth = 0;
-    {
-        struct visit { uint32_t id, depth; };
+    std::vector<wide_node> wide;
+    std::vector<uint32_t> wide_of;  // sah id of each wide node
+    uint32_t tri_cursor = 0, stack_need = 0;
+    if (nodes[0].left < 0) {
+        leaf_first[0] = 0;
+        tri_cursor = nodes[0].count;
+    } else {
+        struct visit { uint32_t id, pending; };  // pending = stack entries that can be live when this node is entered
         std::vector<visit> stack{ { 0, 0 } };
         while (!stack.empty()) {
             const visit v = stack.back();
             stack.pop_back();
-            const sah_node& nd = nodes[v.id];
-            if (nd.left < 0) {
+            if (nodes[v.id].left < 0) {
                 leaf_first[v.id] = tri_cursor;
-                tri_cursor += nd.count;
+                tri_cursor += nodes[v.id].count;
                 continue;
             }
-            flat_index[v.id] = (int32_t)inner_count++;
-            max_depth = std::max(max_depth, v.depth + 1);
-            stack.push_back({ (uint32_t)nd.right, v.depth + 1 });
-            stack.push_back({ (uint32_t)nd.left, v.depth + 1 });
+            const wide_node w = collapse(v.id);
+            wide_index[v.id] = (int32_t)wide.size();
+            wide.push_back(w);
+            wide_of.push_back(v.id);
+            const uint32_t pending = v.pending + (w.count - 1);
+            stack_need = std::max(stack_need, pending);
+            for (int k = (int)w.count - 1; k >= 0; k--) stack.push_back({ (uint32_t)w.child[k], pending });
         }
     }
-    if (max_depth > FLAT_BVH_MAX_DEPTH) throw bvh_build_error("flatten: tree deeper than the traversal stack");
+    if (stack_need > FLAT_BVH_MAX_DEPTH) throw bvh_build_error("flatten: tree needs a deeper traversal stack than the kernels have");
 
-    const size_t nodes_bytes = (size_t)inner_count * sizeof(flat_bvh_node);
+    const size_t nodes_bytes = wide.size() * sizeof(flat_bvh_node);
     const size_t tris_bytes = tris.size() * sizeof(flat_bvh_triangle);
     std::vector<uint8_t> blob(sizeof(flat_bvh_header) + nodes_bytes + tris_bytes, 0);
     auto* header = reinterpret_cast<flat_bvh_header*>(blob.data());
@@ -477,38 +568,47 @@ std::vector<uint8_t> bvh::flatten(const std::vector<triangle>& tris, const std::
 
     auto reference_to = [&](int32_t id) -> int32_t {
         const sah_node& nd = nodes[id];
-        if (nd.left >= 0) return flat_index[id];
+        if (nd.left >= 0) return wide_index[id];
         return ~(int32_t)((leaf_first[id] << 2) | (nd.count - 1));
     };
+
     for (size_t id = 0; id < nodes.size(); id++) {
         const sah_node& nd = nodes[id];
-        if (nd.left < 0) {
-            for (uint32_t k = 0; k < nd.count; k++) {
-                const int32_t prim = order[nd.first + k];
-                fill_flat_triangle(out_tris[leaf_first[id] + k], tris[prim], prim, ranks.empty() ? prim : ranks[prim]);
-            }
-            continue;
+        if (nd.left >= 0) continue;
+        // leaves of collapsed-away inner nodes are still reached through their wide ancestor
+        for (uint32_t k = 0; k < nd.count; k++) {
+            const int32_t prim = order[nd.first + k];
+            fill_flat_triangle(out_tris[leaf_first[id] + k], tris[prim], prim, ranks.empty() ? prim : ranks[prim]);
         }
-        flat_bvh_node& fn = out_nodes[flat_index[id]];
-        const aabb& lb = nodes[nd.left].box;
-        const aabb& rb = nodes[nd.right].box;
+    }
+    for (size_t wi = 0; wi < wide.size(); wi++) {
+        const wide_node& w = wide[wi];
+        const aabb& box = nodes[wide_of[wi]].box;
+        flat_bvh_node& fn = out_nodes[wi];
+        uint32_t biased[3];
+        uint8_t qlo[3][4] = {}, qhi[3][4] = {};
         for (int a = 0; a < 3; a++) {
-            fn.lmin[a] = lb.minimum.v[a]; fn.lmax[a] = lb.maximum.v[a];
-            fn.rmin[a] = rb.minimum.v[a]; fn.rmax[a] = rb.maximum.v[a];
+            float lo[4], hi[4];
+            for (uint32_t k = 0; k < w.count; k++) { lo[k] = nodes[w.child[k]].box.minimum.v[a]; hi[k] = nodes[w.child[k]].box.maximum.v[a]; }
+            quantise_axis(box.minimum.v[a], box.maximum.v[a], lo, hi, w.count, fn.origin[a], biased[a], qlo[a], qhi[a]);
         }
-        fn.left = reference_to(nd.left);
-        fn.right = reference_to(nd.right);
-        fn.pad0 = fn.pad1 = 0;
+        fn.step_x = scale_from_biased(biased[0]);
+        fn.step_y = scale_from_biased(biased[1]);
+        fn.step_z = scale_from_biased(biased[2]);
+        for (uint32_t k = 0; k < 4; k++) fn.child[k] = k < w.count ? reference_to(w.child[k]) : FLAT_BVH_EMPTY_CHILD;
+        auto pack = [](const uint8_t* q) { return (uint32_t)q[0] | ((uint32_t)q[1] << 8) | ((uint32_t)q[2] << 16) | ((uint32_t)q[3] << 24); };
+        fn.qlo[0] = pack(qlo[0]); fn.qlo[1] = pack(qlo[1]); fn.qlo[2] = pack(qlo[2]);
+        fn.qhi_x = pack(qhi[0]); fn.qhi_y = pack(qhi[1]); fn.qhi_z = pack(qhi[2]);
     }
 
     header->magic = FLAT_BVH_MAGIC;
-    header->version = 1;
-    header->node_count = inner_count;
+    header->version = FLAT_BVH_VERSION;
+    header->node_count = (uint32_t)wide.size();
     header->triangle_count = (uint32_t)tris.size();
     header->nodes_offset = sizeof(flat_bvh_header);
     header->triangles_offset = sizeof(flat_bvh_header) + nodes_bytes;
     header->root = reference_to(0);
-    header->max_depth = max_depth;
+    header->max_depth = stack_need;
     for (int a = 0; a < 3; a++) { header->scene_min[a] = nodes[0].box.minimum.v[a]; header->scene_max[a] = nodes[0].box.maximum.v[a]; }
     return blob;
 }

@@ -4,8 +4,8 @@
 //   * build_mode::reference_order  -- the reference's top-down bucketed build (src/bvh.cpp:150-262),
 //     reproduced bit for bit: same threaded 32-byte node array, same depth-first numbering.
 //   * build_mode::sah_partitioned  -- a real binned-SAH build (primitives ARE partitioned).
-//   * flatten()                    -- the GPU layout: 64-byte, cache-line-aligned nodes that hold
-//     both children's boxes, and 64-byte pre-gathered triangle records in leaf order.
+//   * flatten()                    -- the GPU layout: 64-byte, cache-line-aligned nodes of a 4-wide tree
+//     with quantised child boxes, and 64-byte pre-gathered triangle records in leaf order.
 #ifndef PTR_BVH_HPP_
 #define PTR_BVH_HPP_
 
@@ -27,13 +27,20 @@ struct packed_bvh_node {
 static_assert(sizeof(packed_bvh_node) == 32, "threaded node is 32 bytes");
 
 // ---- GPU layout -------------------------------------------------------------------------------
-// One 64-byte line per inner node.  A child reference >= 0 is an inner-node index; < 0 is a leaf:
-// ~ref = (first_triangle << 2) | (triangle_count - 1), 1..4 triangles per leaf.
+// One 64-byte line per inner node of a 4-wide tree.  The node stores an origin just below its own box
+// (fp32) and, per axis, a power-of-two step; the boxes of its up to four children are 8-bit offsets in
+// those steps, rounded outwards with a margin of 2^-20 of the node extent, so a decoded box always
+// contains the true one with room for the kernels' rounding:
+//     decoded = origin + q * step          (q * step is exact, one rounding in the add)
+// Byte k of each q word belongs to child k.  A child reference >= 0 is an inner-node index; < 0 is a leaf:
+// ~ref = (first_triangle << 2) | (triangle_count - 1), 1..4 triangles per leaf; unused slots (always the
+// last ones, children 0 and 1 always exist) hold FLAT_BVH_EMPTY_CHILD.
+// Four 16-byte quarters = four loads per lane for four boxes.
 struct flat_bvh_node {
-    float lmin[3]; int32_t left;
-    float lmax[3]; int32_t right;
-    float rmin[3]; int32_t pad0;
-    float rmax[3]; int32_t pad1;
+    float origin[3]; float step_x;
+    int32_t child[4];
+    uint32_t qlo[3]; uint32_t qhi_x;   // lower bounds x, y, z and upper bound x of the four children
+    uint32_t qhi_y, qhi_z; float step_y, step_z;
 };
 static_assert(sizeof(flat_bvh_node) == 64, "flat node is one 64-byte line");
 
@@ -58,14 +65,16 @@ struct flat_bvh_header {
     uint64_t nodes_offset;     // byte offsets from the start of the blob, 64-byte aligned
     uint64_t triangles_offset;
     int32_t root;              // root reference (a leaf reference when the scene has <= 4 triangles)
-    uint32_t max_depth;        // deepest inner-node chain, bounds the traversal stack
+    uint32_t max_depth;        // most stack entries a traversal can hold at once (bounds the kernels' stacks)
     float scene_min[3];
     float scene_max[3];
 };
 static_assert(sizeof(flat_bvh_header) == 64, "header is one 64-byte line");
 
 constexpr uint32_t FLAT_BVH_MAGIC = 0x46525450u;  // "PTRF"
+constexpr uint32_t FLAT_BVH_VERSION = 2;          // 4-wide nodes with quantised child boxes
 constexpr uint32_t FLAT_BVH_MAX_DEPTH = 62;       // traversal stack capacity in the kernels
+constexpr int32_t FLAT_BVH_EMPTY_CHILD = INT32_MIN;
 
 class bvh_build_error : public std::runtime_error {
 public:

@@ -20,7 +20,7 @@ def test_layout_invariants():
     b = make_bundle("atrium", 6000)
     h, nodes, tris = parse(b["flat"])
     n = b["triangles"].shape[0]
-    assert h["magic"] == 0x46525450 and h["version"] == 1 and h["triangle_count"] == n
+    assert h["magic"] == 0x46525450 and h["version"] == 2 and h["triangle_count"] == n
     assert h["nodes_offset"] % 64 == 0 and h["triangles_offset"] % 64 == 0 and b["flat"].nbytes == 64 + 64 * (h["node_count"] + n)
     ti = tris.view(np.int32)
     assert sorted(ti[:, 7].tolist()) == list(range(n))                        # every primitive exactly once
@@ -33,31 +33,52 @@ def test_layout_invariants():
                     e1[:, 0] * e2[:, 1] - e2[:, 0] * e1[:, 1]], 1)
     assert np.array_equal(tris[:, 12:15], nrm)
 
-    # walk the tree: child boxes contain their subtrees, leaves hold 1..4 triangles and tile the triangle array
+    # walk the 4-wide tree: every decoded child box contains its subtree (conservative quantisation, within one
+    # step of the true bound), leaves hold 1..4 triangles and tile the triangle array, the stack bound holds
     ni = nodes.view(np.int32)
+    nu = nodes.view(np.uint32)
     seen = np.zeros(n, bool)
     tmin, tmax = tri.min(axis=1), tri.max(axis=1)
-    max_depth = 0
+    EMPTY = -2 ** 31
+    worst_stack = 0
 
-    def bounds_of(ref, depth):
-        nonlocal max_depth
+    def bounds_of(ref, pending):
+        nonlocal worst_stack
         if ref < 0:
             first, cnt = (~ref) >> 2, ((~ref) & 3) + 1
             assert not seen[first:first + cnt].any()
             seen[first:first + cnt] = True
             return tmin[first:first + cnt].min(axis=0), tmax[first:first + cnt].max(axis=0)
-        max_depth = max(max_depth, depth + 1)
         nd = nodes[ref]
-        lo_l, hi_l = bounds_of(int(ni[ref, 3]), depth + 1)
-        lo_r, hi_r = bounds_of(int(ni[ref, 7]), depth + 1)
-        assert np.array_equal(nd[0:3], lo_l) and np.array_equal(nd[4:7], hi_l)
-        assert np.array_equal(nd[8:11], lo_r) and np.array_equal(nd[12:15], hi_r)
-        return np.minimum(lo_l, lo_r), np.maximum(hi_l, hi_r)
+        count = sum(1 for k in range(4) if int(ni[ref, 4 + k]) != EMPTY)
+        assert 2 <= count <= 4
+        step = np.array([nd[3], nd[14], nd[15]], dtype=np.float32)
+        assert all(float(x) > 0 and np.frexp(x)[0] == 0.5 for x in step), "steps are powers of two"
+        worst_stack = max(worst_stack, pending + count - 1)
+        lo_all, hi_all = [], []
+        for k in range(4):
+            child = int(ni[ref, 4 + k])
+            if k >= count:
+                assert child == EMPTY
+                continue
+            assert child != EMPTY
+            qlo = np.array([(int(nu[ref, 8 + a]) >> (8 * k)) & 0xFF for a in range(3)], dtype=np.float32)
+            qhi = np.array([(int(nu[ref, 11 + a]) >> (8 * k)) & 0xFF for a in range(3)], dtype=np.float32)  # words 11, 12, 13
+            dlo = nd[0:3] + qlo * step
+            dhi = nd[0:3] + qhi * step
+            lo, hi = bounds_of(child, pending + count - 1)
+            assert (dlo <= lo).all() and (dhi >= hi).all(), "decoded box must contain the subtree"
+            assert (lo - dlo <= step * 2.001 + 1e-30).all() and (dhi - hi <= step * 2.001 + 1e-30).all(), "and be tight to two steps"
+            lo_all.append(lo); hi_all.append(hi)
+        lo, hi = np.min(lo_all, axis=0), np.max(hi_all, axis=0)
+        slack = (hi - lo) * 2e-6 + 2 * np.spacing(np.abs(lo).astype(np.float32)) + 1e-29
+        assert (nd[0:3] < lo).all() and (lo - nd[0:3] <= slack).all(), "node origin sits a margin below the true box minimum"
+        return lo, hi
 
     import sys
     sys.setrecursionlimit(10000)
     lo, hi = bounds_of(h["root"], 0)
-    assert seen.all() and max_depth == h["max_depth"] <= 62
+    assert seen.all() and worst_stack <= h["max_depth"] <= 62
     assert np.array_equal(lo, h["scene_min"]) and np.array_equal(hi, h["scene_max"])
 
 
@@ -91,7 +112,7 @@ def test_flat_traversal_agrees_with_reference_order_traversal_on_random_rays():
         if hr != hf or (hr and (pr.value != pf.value or tr.value != tf.value or not np.array_equal(br, bf))):
             mismatches += 1
     assert mismatches == 0
-    assert c_flat.nodes * 4 < c_ref.nodes   # the point of the exercise: far fewer node fetches per ray
+    assert c_flat.nodes * 8 < c_ref.nodes   # the point of the exercise: far fewer node fetches per ray
 
 
 def test_flat_and_reference_order_images_agree():
