@@ -66,7 +66,7 @@ struct ptr_ctx {
     ptr::WavefrontScratch scratch{};
     void* scratch_block = nullptr;
     int cu_count = 256;
-    int opt_extend_inner_reps = 2;  // inner-node steps per inner turn
+    int opt_extend_inner_reps = 3;  // inner-node steps per inner turn
     int opt_extend_leaf_all = 1;    // 1: a leaf turn tests every triangle of the leaf, 0: one triangle per turn
     int opt_extend_leaf_weight = 2; // leaf lanes count this many times when a traversal wave picks its next step kind
     int opt_extend_refill = 16;     // idle lanes that trigger a refill of the traversal wave (8, 16, 32, 48, 64)
@@ -180,8 +180,8 @@ int ensure_scratch(ptr_ctx* c, uint32_t capacity) {
     const size_t cap = ((size_t)capacity + 255) & ~(size_t)255;
     const uint32_t extend_blocks = (uint32_t)c->cu_count * (uint32_t)c->opt_extend_blocks_per_cu;
     const size_t spill_words = (size_t)extend_blocks * (ptr::kExtendThreads / 64) * ptr::kStackSpill * 64;
-    // 2 generations x (6 ray + 3 throughput + seed + pixel) words, hits + samples (4 words each), counters, spill
-    const size_t words = cap * (2 * 11 + 8) + 64 + spill_words;
+    // 2 generations x 3 records of 4 words, hits + samples (4 words each), counters, spill
+    const size_t words = cap * (2 * 12 + 8) + 64 + spill_words;
     PTR_HIP_CHECK(c, hipMalloc(&c->scratch_block, words * 4));
     uint32_t* p = (uint32_t*)c->scratch_block;
     auto take = [&](size_t n) { uint32_t* r = p; p += n; return r; };
@@ -189,10 +189,9 @@ int ensure_scratch(ptr_ctx* c, uint32_t capacity) {
     s.hits = (float4*)take(cap * 4);
     s.samples = (float4*)take(cap * 4);
     for (int g = 0; g < 2; g++) {
-        for (int k = 0; k < 6; k++) s.ray[g][k] = (float*)take(cap);
-        for (int k = 0; k < 3; k++) s.throughput[g][k] = (float*)take(cap);
-        s.seed[g] = take(cap);
-        s.pixel[g] = take(cap);
+        s.ray_o[g] = (float4*)take(cap * 4);
+        s.ray_d[g] = (float4*)take(cap * 4);
+        s.path_t[g] = (float4*)take(cap * 4);
     }
     s.counters = take(64);
     s.stack_spill = (int32_t*)take(spill_words);

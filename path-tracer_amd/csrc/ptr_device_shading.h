@@ -166,12 +166,22 @@ PTR_DEV float fract_repeat(float x) {
     if (!(fr == fr)) fr = 0.0f;
     return fr;
 }
+// b / 255 for a byte b, correctly rounded, without the division sequence: one multiply by RN(1/255) and one
+// residual correction (f' = f + (b - 255 f) / 255, both steps fused).  Equal to the IEEE quotient for all 256
+// inputs (checked exhaustively in tests/test_device_identities.py), at 3 instructions instead of ~12.
+PTR_DEV float unorm8(uint32_t b) {
+    const float k = 1.0f / 255.0f;
+    const float fb = (float)b;
+    const float f = fb * k;
+    const float r = __builtin_fmaf(-f, 255.0f, fb);
+    return __builtin_fmaf(r, k, f);
+}
 PTR_DEV f4 unpack_rgba8(uint32_t p) {
     f4 r;
-    r.x = (float)(p & 0xffu) / 255.0f;
-    r.y = (float)((p >> 8) & 0xffu) / 255.0f;
-    r.z = (float)((p >> 16) & 0xffu) / 255.0f;
-    r.w = (float)(p >> 24) / 255.0f;
+    r.x = unorm8(p & 0xffu);
+    r.y = unorm8((p >> 8) & 0xffu);
+    r.z = unorm8((p >> 16) & 0xffu);
+    r.w = unorm8(p >> 24);
     return r;
 }
 PTR_DEV f4 sample_bindless(const SceneView& sv, uint32_t texture_id, float u, float v) {

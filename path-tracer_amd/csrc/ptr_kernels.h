@@ -19,11 +19,11 @@ struct FlatView {
 
 // Scratch of the wavefront pipeline, owned by the context, sized for `capacity` paths.
 struct WavefrontScratch {
-    // ray + path state, structure-of-arrays, two generations (read bounce b, write bounce b+1)
-    float* ray[2][6];       // origin xyz, direction xyz
-    float* throughput[2][3];
-    uint32_t* seed[2];
-    uint32_t* pixel[2];     // gy * width + gx of the dispatch
+    // ray + path state, three 16-byte records per path in three arrays (every access of a wave is one
+    // contiguous 1 KiB run), two generations (read bounce b, write bounce b+1):
+    float4* ray_o[2];       // origin.xyz, pixel (bits; gy * width + gx of the dispatch, 0xffffffff = empty slot)
+    float4* ray_d[2];       // direction.xyz, RNG state (bits)
+    float4* path_t[2];      // throughput.xyz, unused
     float4* hits;           // t, u, v, prim (bits)
     float4* samples;        // per pixel: the sample's colour (w unused)
     uint32_t* counters;     // [0..15]: live paths entering bounce b; [16..31]: fetch cursors of the extend kernel

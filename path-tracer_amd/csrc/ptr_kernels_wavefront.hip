@@ -7,7 +7,7 @@
 //              compacted into the next generation's queues (ballot + one atomic per wave)
 //   accumulate one lane per pixel: temporal mean with the accumulation image -> output image
 //
-// Queues are structure-of-arrays so that every load/store of a wave is one contiguous 256-byte run.
+// Queues are arrays of 16-byte records so that every load/store of a wave is one contiguous 1 KiB run.
 // Results do not depend on queue order: a path carries its pixel index, RNG state and throughput.
 #pragma clang fp contract(off)
 
@@ -49,11 +49,9 @@ __global__ __launch_bounds__(256) void ptr_wf_generate(SceneView sv, WavefrontSc
         if (sv.capture) { Capture c; c.prim0 = -1; c.t0 = 0.0f; c.prim1 = -1; c.t1 = 0.0f; sv.capture[(size_t)gy * m.width + gx] = c; }
     }
     const uint32_t slot = wave * 64u + lane;
-    w.ray[0][0][slot] = r.origin.x; w.ray[0][1][slot] = r.origin.y; w.ray[0][2][slot] = r.origin.z;
-    w.ray[0][3][slot] = r.dir.x; w.ray[0][4][slot] = r.dir.y; w.ray[0][5][slot] = r.dir.z;
-    w.throughput[0][0][slot] = 1.0f; w.throughput[0][1][slot] = 1.0f; w.throughput[0][2][slot] = 1.0f;
-    w.seed[0][slot] = seed;
-    w.pixel[0][slot] = valid ? gy * m.width + gx : kInvalidPixel;
+    w.ray_o[0][slot] = make_float4(r.origin.x, r.origin.y, r.origin.z, __uint_as_float(valid ? gy * m.width + gx : kInvalidPixel));
+    w.ray_d[0][slot] = make_float4(r.dir.x, r.dir.y, r.dir.z, __uint_as_float(seed));
+    w.path_t[0][slot] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
 }
 
 // ---- extend --------------------------------------------------------------------------------------------
@@ -142,10 +140,13 @@ __global__ __launch_bounds__(kExtendThreads, 4) void ptr_wf_extend(FlatView fv, 
                 const uint32_t k = next_k + (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
                 if (k < my_rays) {
                     const uint32_t idx = ((k >> 6) * total_waves + global_wave) * 64u + (k & 63u);
-                    if (idx < count && w.pixel[gen][idx] != kInvalidPixel) {
+                    float4 ro = make_float4(0, 0, 0, __uint_as_float(kInvalidPixel));
+                    if (idx < count) ro = w.ray_o[gen][idx];
+                    if (__float_as_uint(ro.w) != kInvalidPixel) {
+                        const float4 rd = w.ray_d[gen][idx];
                         slot = idx;
-                        o = mk3(w.ray[gen][0][idx], w.ray[gen][1][idx], w.ray[gen][2][idx]);
-                        d = mk3(w.ray[gen][3][idx], w.ray[gen][4][idx], w.ray[gen][5][idx]);
+                        o = mk3(ro.x, ro.y, ro.z);
+                        d = mk3(rd.x, rd.y, rd.z);
                         inv = mk3(rcp(d.x), rcp(d.y), rcp(d.z));
                         neg_x = (as_u32(inv.x) >> 31) != 0u; neg_y = (as_u32(inv.y) >> 31) != 0u; neg_z = (as_u32(inv.z) >> 31) != 0u;
                         best_t = 1e15f; best_u = 0.0f; best_v = 0.0f; best_rank = -1; best_prim = -1;
@@ -273,7 +274,7 @@ __global__ __launch_bounds__(kExtendThreads, 4) void ptr_wf_extend(FlatView fv, 
 }
 
 // ---- shade ---------------------------------------------------------------------------------------------
-constexpr uint32_t kShadeThreads = 1024;
+constexpr uint32_t kShadeThreads = 512;
 
 // Survivors of a 1024-lane block are compacted with ONE atomic on the next queue's counter: ballots give the
 // per-wave counts, lane 0 of the block turns them into offsets.  (A single address sustains only ~90 atomics
@@ -287,8 +288,9 @@ __global__ __launch_bounds__(kShadeThreads) void ptr_wf_shade(SceneView sv, Wave
     if (blockIdx.x * kShadeThreads >= count) return;  // uniform for the block
     const uint32_t i = blockIdx.x * kShadeThreads + threadIdx.x;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    uint32_t pixel = kInvalidPixel;
-    if (i < count) pixel = w.pixel[gen][i];
+    float4 ro = make_float4(0, 0, 0, __uint_as_float(kInvalidPixel));
+    if (i < count) ro = w.ray_o[gen][i];
+    const uint32_t pixel = __float_as_uint(ro.w);
     const bool live = pixel != kInvalidPixel;
 
     bool go_on = false;
@@ -297,10 +299,11 @@ __global__ __launch_bounds__(kShadeThreads) void ptr_wf_shade(SceneView sv, Wave
     uint32_t seed = 0u;
     unsigned long long shaded = 0;
     if (live) {
-        r.origin = mk3(w.ray[gen][0][i], w.ray[gen][1][i], w.ray[gen][2][i]);
-        r.dir = mk3(w.ray[gen][3][i], w.ray[gen][4][i], w.ray[gen][5][i]);
-        throughput = mk3(w.throughput[gen][0][i], w.throughput[gen][1][i], w.throughput[gen][2][i]);
-        seed = w.seed[gen][i];
+        const float4 rd = w.ray_d[gen][i], pt = w.path_t[gen][i];
+        r.origin = mk3(ro.x, ro.y, ro.z);
+        r.dir = mk3(rd.x, rd.y, rd.z);
+        throughput = mk3(pt.x, pt.y, pt.z);
+        seed = __float_as_uint(rd.w);
         const float4 h4 = w.hits[i];
         Hit h; h.t = h4.x; h.u = h4.y; h.v = h4.z; h.prim = __float_as_int(h4.w);
         if (STATS && h.prim >= 0) shaded = 1;
@@ -326,11 +329,9 @@ __global__ __launch_bounds__(kShadeThreads) void ptr_wf_shade(SceneView sv, Wave
     if (go_on) {
         const uint32_t next = gen ^ 1u;
         const uint32_t slot = block_base + wave_offset[wave] + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-        w.ray[next][0][slot] = r.origin.x; w.ray[next][1][slot] = r.origin.y; w.ray[next][2][slot] = r.origin.z;
-        w.ray[next][3][slot] = r.dir.x; w.ray[next][4][slot] = r.dir.y; w.ray[next][5][slot] = r.dir.z;
-        w.throughput[next][0][slot] = throughput.x; w.throughput[next][1][slot] = throughput.y; w.throughput[next][2][slot] = throughput.z;
-        w.seed[next][slot] = seed;
-        w.pixel[next][slot] = pixel;
+        w.ray_o[next][slot] = make_float4(r.origin.x, r.origin.y, r.origin.z, __uint_as_float(pixel));
+        w.ray_d[next][slot] = make_float4(r.dir.x, r.dir.y, r.dir.z, __uint_as_float(seed));
+        w.path_t[next][slot] = make_float4(throughput.x, throughput.y, throughput.z, 0.0f);
     }
     if (STATS && sv.stats) {
         for (int off = 32; off > 0; off >>= 1) shaded += __shfl_down(shaded, off);

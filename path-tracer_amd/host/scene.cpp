@@ -1,0 +1,142 @@
+#include "scene.hpp"
+
+#include <cstdio>
+#include <cstring>
+#include <stdexcept>
+
+#include "bvh.hpp"
+#include "hip-renderer.hpp"
+
+scene::metadata::metadata(const camera& cam_, uint32_t width_, uint32_t height_) : cam(cam_), width(width_), height(height_) {}
+
+// .ptrscene: little-endian, "PTRS", u32 version = 1, u32 index_words, u32 vertices, u32 materials, u32 textures,
+// then indices, positions, normals, uvs, materials (48 bytes: base_color[4], albedo texture, unused, mr texture,
+// unused, metalness, roughness, pad[2]), then per texture u32 width, u32 height, RGBA8 texels.
+scene_source scene_source::load(const std::string& path) {
+    FILE* f = std::fopen(path.c_str(), "rb");
+    if (!f) throw std::runtime_error("scene_source::load: cannot open " + path);
+    auto read = [&](void* dst, size_t n) { if (n && std::fread(dst, 1, n, f) != n) { std::fclose(f); throw std::runtime_error("scene_source::load: truncated " + path); } };
+    uint32_t head[6];
+    read(head, sizeof head);
+    if (std::memcmp(&head[0], "PTRS", 4) != 0 || head[1] != 1) { std::fclose(f); throw std::runtime_error("scene_source::load: not a .ptrscene v1 file"); }
+    scene_source s;
+    s.indices.resize(head[2]);
+    s.positions.resize((size_t)head[3] * 3);
+    s.normals.resize((size_t)head[3] * 3);
+    s.uvs.resize((size_t)head[3] * 2);
+    read(s.indices.data(), s.indices.size() * 4);
+    read(s.positions.data(), s.positions.size() * 4);
+    read(s.normals.data(), s.normals.size() * 4);
+    read(s.uvs.data(), s.uvs.size() * 4);
+    for (uint32_t i = 0; i < head[4]; i++) {
+        struct { float base_color[4]; uint32_t albedo, albedo_sampler, mr, mr_sampler; float metalness, roughness, pad[2]; } m;
+        read(&m, sizeof m);
+        source_material sm;
+        std::memcpy(sm.base_color, m.base_color, sizeof sm.base_color);
+        sm.albedo_texture = m.albedo; sm.mr_texture = m.mr; sm.metalness = m.metalness; sm.roughness = m.roughness;
+        s.materials.push_back(sm);
+    }
+    for (uint32_t i = 0; i < head[5]; i++) {
+        uint32_t wh[2];
+        read(wh, sizeof wh);
+        source_texture t;
+        t.width = wh[0]; t.height = wh[1];
+        t.rgba.resize((size_t)wh[0] * wh[1] * 4);
+        read(t.rgba.data(), t.rgba.size());
+        s.textures.push_back(std::move(t));
+    }
+    std::fclose(f);
+    return s;
+}
+
+scene::scene(const camera& cam, uint32_t width, uint32_t height, const scene_source& src, bool flatten_bvh) : meta(cam, width, height) {
+    if (src.indices.empty() || src.indices.size() % 3) throw std::runtime_error("scene: index count must be a positive multiple of 3");
+    const size_t vertex_count = src.positions.size() / 3;
+    if (vertex_count >= (1u << 24)) throw std::runtime_error("scene: more than 2^24 vertices do not fit the packed index words");
+    if (src.materials.size() >= (1u << 24)) throw std::runtime_error("scene: more than 2^24 materials");
+
+    // textures + the one LINEAR / REPEAT sampler the reference creates (src/gltf.cpp:118)
+    sampler = hiprenderer::create_sampler(PTR_FILTER_LINEAR, PTR_ADDRESS_REPEAT);
+    for (const auto& t : src.textures) {
+        Texture* tex = hiprenderer::create_2d_texture(t.width, t.height, PTR_FORMAT_RGBA8_UNORM, sampler);
+        tex->update(t.rgba.data());
+        textures.push_back(tex);
+    }
+    uint32_t sampler_index = 0;
+    hiprenderer::check(ptr_sampler_index(hiprenderer::api, sampler->device_sampler, &sampler_index), "ptr_sampler_index");
+
+    // one gpu_material per primitive with bindless indices (src/scene.cpp:145-163); 0 = no texture = white
+    std::vector<gpu_material> materials;
+    for (const auto& m : src.materials) {
+        gpu_material g;
+        g.base_color = color(m.base_color[0], m.base_color[1], m.base_color[2]);
+        g.base_color.v[3] = m.base_color[3];
+        auto bind = [&](uint32_t number, uint32_t& tex_id, uint32_t& sampler_id) {
+            if (number == 0) return;
+            if (number > textures.size()) throw std::runtime_error("scene: material names a texture that does not exist");
+            tex_id = textures[number - 1]->bindless_index();
+            sampler_id = sampler_index;
+        };
+        bind(m.albedo_texture, g.albedo_texture_id, g.albedo_texture_sampler_id);
+        bind(m.mr_texture, g.metallic_roughness_texture_id, g.metallic_roughness_texture_sampler_id);
+        g.metalness = m.metalness;
+        g.roughness = m.roughness;
+        materials.push_back(g);
+    }
+
+    // triangles for the builder: corners fetched through the 24-bit vertex indices (src/scene.cpp:132-136)
+    std::vector<triangle> triangles;
+    triangles.reserve(src.indices.size() / 3);
+    for (size_t i = 0; i < src.indices.size(); i += 3) {
+        vec3 p[3];
+        for (int k = 0; k < 3; k++) {
+            const uint32_t v = src.indices[i + k] & 0x00ffffffu;
+            if (v >= vertex_count) throw std::runtime_error("scene: vertex index out of range");
+            p[k] = vec3(src.positions[v * 3], src.positions[v * 3 + 1], src.positions[v * 3 + 2]);
+        }
+        triangles.emplace_back(p[0], p[1], p[2]);
+    }
+    triangle_count = triangles.size();
+
+    std::vector<packed_bvh_node> packed_nodes;
+    std::vector<int32_t> ranks;
+    try {
+        bvh builder(triangles, packed_nodes);
+        ranks = bvh::visit_ranks(packed_nodes, triangles.size());
+        bvh_mode = "reference_order";
+    } catch (const bvh_build_error&) {
+        // the reference's builder cannot finish on this input; keep the same node format with a real SAH split
+        bvh builder(triangles, packed_nodes, bvh::build_mode::sah_partitioned);
+        bvh_mode = "sah_partitioned";
+    }
+
+    scene_buffer = hiprenderer::create_buffer(sizeof(meta) * hiprenderer::virtual_frames_count);
+    upload_metadata();
+    scene_buffer->write(&meta, sizeof(meta), sizeof(meta));
+
+    auto upload = [](const void* data, size_t bytes) {
+        Buffer* b = hiprenderer::create_buffer(bytes);
+        b->write(data, 0, bytes);
+        return b;
+    };
+    indices_buffer = upload(src.indices.data(), src.indices.size() * sizeof(uint32_t));
+    positions_buffer = upload(src.positions.data(), src.positions.size() * sizeof(float));
+    normals_buffer = upload(src.normals.data(), src.normals.size() * sizeof(float));
+    uvs_buffer = upload(src.uvs.data(), src.uvs.size() * sizeof(float));
+    bvh_buffer = upload(packed_nodes.data(), packed_nodes.size() * sizeof(packed_bvh_node));
+    materials_buffer = upload(materials.data(), materials.size() * sizeof(gpu_material));
+
+    if (flatten_bvh) {
+        const std::vector<uint8_t> flat = bvh::flatten(triangles, ranks);
+        flat_bvh_buffer = upload(flat.data(), flat.size());
+        hiprenderer::check(ptr_bvh_bind_flat(hiprenderer::api, bvh_buffer->device_buffer, flat_bvh_buffer->device_buffer), "ptr_bvh_bind_flat");
+    }
+}
+
+void scene::upload_metadata() const { scene_buffer->write(&meta, 0, sizeof(meta)); }
+
+scene::~scene() {
+    for (Buffer* b : { scene_buffer, indices_buffer, positions_buffer, normals_buffer, uvs_buffer, bvh_buffer, materials_buffer, flat_bvh_buffer }) delete b;
+    for (Texture* t : textures) delete t;
+    delete sampler;
+}

@@ -1,0 +1,80 @@
+// Scene: owns the per-frame metadata block and the seven device buffers the kernels read, with the member
+// names of the reference (include/scene.hpp:10-43).  The reference's constructor parses a hard-coded glTF
+// file; here the flattened arrays come from a `scene_source` (a glTF loader or a .ptrscene file fills it),
+// and the flattening that follows is the reference's (src/scene.cpp:84-204) with its buffer-sizing bugs fixed.
+#ifndef PTR_SCENE_HPP_
+#define PTR_SCENE_HPP_
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "camera.hpp"
+#include "material.hpp"
+
+class Buffer;
+class Texture;
+class Sampler;
+
+// Flat scene arrays, i.e. what src/scene.cpp:84-176 produces from the glTF node tree.
+struct scene_source {
+    std::vector<uint32_t> indices;     // 3 per triangle: 24-bit vertex index | one byte of the 24-bit material id
+    std::vector<float> positions;      // 3 per vertex
+    std::vector<float> normals;        // 3 per vertex
+    std::vector<float> uvs;            // 2 per vertex
+    struct source_material { float base_color[4]; uint32_t albedo_texture, mr_texture; float metalness, roughness; };
+    std::vector<source_material> materials;  // texture numbers are 1-based indices into `textures`, 0 = none
+    struct source_texture { uint32_t width, height; std::vector<uint8_t> rgba; };
+    std::vector<source_texture> textures;
+
+    static scene_source load(const std::string& path);  // .ptrscene file, see scene.cpp
+};
+
+class scene {
+public:
+    struct metadata {
+        camera cam;
+
+        uint32_t max_bounce = 3;
+        uint32_t min_bounce = 1;
+
+        uint32_t width;
+        uint32_t height;
+
+        uint32_t sample_index = 1;  // the reference starts at 0 and divides by it; 1 is the first valid sample
+
+        uint32_t enable_dof = 0;
+        uint32_t debug_bvh = 0;
+        int32_t downscale_factor = 1;
+
+        metadata(const camera& cam, uint32_t width, uint32_t height);
+    };
+    static_assert(sizeof(camera) == 128, "camera block");
+
+    scene(const camera& cam, uint32_t width, uint32_t height, const scene_source& source, bool flatten_bvh = true);
+    ~scene();
+
+    // Writes `meta` where the kernels read it (slot 0 of the scene buffer).
+    void upload_metadata() const;
+
+    metadata meta;
+
+    Buffer* scene_buffer = nullptr;
+    Buffer* indices_buffer = nullptr;
+    Buffer* positions_buffer = nullptr;
+    Buffer* normals_buffer = nullptr;
+    Buffer* uvs_buffer = nullptr;
+    Buffer* bvh_buffer = nullptr;
+    Buffer* materials_buffer = nullptr;
+    Buffer* flat_bvh_buffer = nullptr;  // the flattened layout bound to bvh_buffer (wavefront path), may be null
+
+    size_t triangle_count = 0;
+    std::string bvh_mode;               // "reference_order" or "sah_partitioned"
+
+private:
+    Sampler* sampler = nullptr;
+    std::vector<Texture*> textures;
+};
+static_assert(sizeof(scene::metadata) == 160, "scene metadata is 160 bytes");
+
+#endif  // PTR_SCENE_HPP_

@@ -19,7 +19,14 @@ def build_hip(jobs=4):
     return paths.HIP_LIB
 
 
+def build_headless():
+    """The C++ headless driver (links libptr_hip.so through its C ABI)."""
+    _make(paths.HOST, "ptr_headless")
+    return os.path.join(paths.HOST, "ptr_headless")
+
+
 def build_all():
     build_host()
     build_hip()
+    build_headless()
     assert os.path.exists(paths.HOST_LIB) and os.path.exists(paths.HIP_LIB)

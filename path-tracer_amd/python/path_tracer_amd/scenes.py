@@ -351,3 +351,20 @@ def pack_metadata(camera_block, width, height, max_bounce=3, min_bounce=1, sampl
     u[32:39] = [max_bounce, min_bounce, width, height, sample_index, enable_dof, debug_bvh]
     meta.view(np.int32)[39] = downscale_factor
     return meta
+
+
+def save_ptrscene(scene, path):
+    """Writes the flat arrays in the .ptrscene layout the C++ host reads (host/scene.cpp: scene_source::load)."""
+    textures = [t for t in scene["textures"] if t is not None]
+    with open(path, "wb") as f:
+        n_vertices = len(scene["positions"]) // 3
+        f.write(b"PTRS")
+        f.write(np.array([1, len(scene["indices"]), n_vertices, len(scene["materials"]), len(textures)], dtype="<u4").tobytes())
+        f.write(np.ascontiguousarray(scene["indices"], dtype="<u4").tobytes())
+        f.write(np.ascontiguousarray(scene["positions"], dtype="<f4").tobytes())
+        f.write(np.ascontiguousarray(scene["normals"], dtype="<f4").tobytes())
+        f.write(np.ascontiguousarray(scene["uvs"], dtype="<f4").tobytes())
+        f.write(np.ascontiguousarray(scene["materials"]).tobytes())
+        for t in textures:
+            f.write(np.array([t.shape[1], t.shape[0]], dtype="<u4").tobytes())
+            f.write(np.ascontiguousarray(t, dtype=np.uint8).tobytes())

@@ -1,0 +1,51 @@
+"""The C++ host path end to end: .ptrscene -> scene / bvh / camera classes -> ComputeRenderpass -> C ABI -> HIP,
+driven by the headless replacement of the reference's main().  Its image must equal the CPU oracle's."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from common import make_bundle, oracle_frames
+from path_tracer_amd import paths, scenes
+
+pytestmark = pytest.mark.gpu
+HEADLESS = os.path.join(paths.HOST, "ptr_headless")
+
+
+def read_ptrf(path):
+    with open(path, "rb") as f:
+        magic, w, h = f.readline().split()
+        assert magic == b"PTRF"
+        return np.frombuffer(f.read(), dtype=np.float32).reshape(int(h), int(w), 4)
+
+
+@pytest.mark.parametrize("pipeline,use_flat", [("compute.megakernel", False), ("compute", True)])
+def test_headless_driver_matches_oracle(tmp_path, pipeline, use_flat):
+    if not os.path.exists(HEADLESS):
+        pytest.fail(f"{HEADLESS} is not built (make -C path-tracer_amd/host ptr_headless)")
+    W, H, SPP = 72, 40, 3
+    b = make_bundle("atrium", 3000, W, H, max_bounce=4)
+    scene_file = str(tmp_path / "scene.ptrscene")
+    out_file = str(tmp_path / "out.pfm")
+    scenes.save_ptrscene(b, scene_file)
+    c = b["camera"]
+    cmd = [HEADLESS, "--scene", scene_file, "--width", str(W), "--height", str(H), "--spp", str(SPP), "--max-bounce", "4",
+           "--pipeline", pipeline, "--out", out_file, "--pos", *map(str, c["pos"]), "--target", *map(str, c["target"]),
+           "--fov", str(c["v_fov"]), "--aperture", str(c["aperture"]), "--focus", str(c["focus"])]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    img = read_ptrf(out_file)
+    ref, _, _ = oracle_frames(b, SPP, use_flat=use_flat)
+    assert np.array_equal(img, ref), f"{int((np.abs(img - ref).max(axis=2) > 0).sum())} pixels differ\n{r.stderr}"
+
+    ppm = str(tmp_path / "out.ppm")
+    r = subprocess.run(cmd[:cmd.index("--out") + 1] + [ppm] + cmd[cmd.index("--out") + 2:], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    head = open(ppm).read().split()[:4]
+    assert head == ["P3", str(W), str(H), "255"]
+
+
+def test_headless_reports_errors():
+    r = subprocess.run([HEADLESS, "--scene", "/nonexistent.ptrscene"], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 1 and "cannot open" in r.stderr
