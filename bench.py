@@ -109,10 +109,18 @@ def main():
         log(rank, f"note: --gpus {args.gpus} but WORLD_SIZE {world}; using WORLD_SIZE")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the render path has no CPU fallback")
+    # PTR_BENCH_DEVICE / PTR_BENCH_BACKEND exist to rehearse the multi-rank path on a one-GPU box
+    # (all ranks on one device, gloo instead of RCCL); the driver's runs use neither.
+    if "PTR_BENCH_DEVICE" in os.environ:
+        local_rank = int(os.environ["PTR_BENCH_DEVICE"])
+    backend = os.environ.get("PTR_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from path_tracer_amd import distributed as ptdist
     from path_tracer_amd import hip
@@ -187,8 +195,9 @@ def main():
         ctx.stats_enable(False)
         torch.cuda.synchronize()
 
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        work = torch.tensor([stats["rays"], stats["nodes"], stats["triangles"], stats["shaded"]], dtype=torch.float64, device="cuda")
+        reduce_device = "cuda" if backend == "nccl" else "cpu"
+        t = torch.tensor([elapsed], dtype=torch.float64, device=reduce_device)
+        work = torch.tensor([stats["rays"], stats["nodes"], stats["triangles"], stats["shaded"]], dtype=torch.float64, device=reduce_device)
         if world > 1:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dist.all_reduce(work, op=dist.ReduceOp.SUM)

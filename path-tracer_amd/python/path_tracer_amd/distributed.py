@@ -55,5 +55,11 @@ def gather_tiles(image, rank, world, stripe_rows, group=None):
 def allreduce_linear(image_linear, group=None):
     """Sums the linearized per-GPU means in place (alpha carries the number of contributions)."""
     if dist.is_initialized() and dist.get_world_size(group) > 1:
-        dist.all_reduce(image_linear, op=dist.ReduceOp.SUM, group=group)
+        if image_linear.is_cuda and dist.get_backend(group) == "gloo":
+            # rehearsal path (gloo has no device collectives here): stage through host memory
+            staged = image_linear.cpu()
+            dist.all_reduce(staged, op=dist.ReduceOp.SUM, group=group)
+            image_linear.copy_(staged)
+        else:
+            dist.all_reduce(image_linear, op=dist.ReduceOp.SUM, group=group)
     return image_linear
