@@ -125,6 +125,21 @@ int ptr_profile_read(ptr_ctx* ctx, const char* kernel_name, uint64_t* launches, 
 /* Names the profiler knows, '\n'-separated, into dst (size bytes incl. NUL). */
 int ptr_profile_names(ptr_ctx* ctx, char* dst, size_t size);
 
+/* Evaluates ONE device function of the shader on `count` argument records (host arrays of 32-bit words; floats
+ * as their bit patterns) and returns the result records, for known-answer tests of the device code at function
+ * granularity.  Names and record layouts (words in -> words out):
+ *   "pcg_hash" 1->2, "rand" 1->2 (shaders/include/rand.h:1-12; out = value, advanced state);
+ *   "sin" 1->1, "cos" 1->1, "pow" 2->1 (the GLSL built-ins used by math.h / brdf.h / color_utils.h);
+ *   "srgb_to_linear" 3->3, "linear_to_srgb" 3->3 (color_utils.h:1-21);
+ *   "hit_aabb" min[3] max[3] origin[3] dir[3] min_t max_t -> hit (ray.h:66-78);
+ *   "hit_triangle" p0[3] p1[3] p2[3] origin[3] dir[3] min_t max_t -> hit, t, bary[3], normal[3] (ray.h:137-163);
+ *   "hit_sphere" centre[3] radius origin[3] dir[3] min_t max_t -> hit, t (ray.h:105-135);
+ *   "rotation_to_z_axis" 3->4, "rotate_point" q[4] v[3] -> 3, "sample_hemisphere" 2->3, "disk_vec" 2->2 (math.h:12-45);
+ *   "sample_ggx_vndf" ve[3] ax ay seed -> 3, "brdf_probability" colour[3] metalness view[3] normal[3] -> 1 (brdf.h:13-35,83-99).
+ * in_words / out_words must equal the function's record sizes (PTR_E_INVALID otherwise). Synchronous. */
+int ptr_device_function(ptr_ctx* ctx, const char* name, const uint32_t* in, uint32_t in_words, uint32_t* out, uint32_t out_words,
+                        uint32_t count);
+
 #ifdef __cplusplus
 }
 #endif

@@ -540,6 +540,33 @@ int ptr_image_read(ptr_ctx* c, ptr_handle h, void* texels) {
     return PTR_OK;
 }
 
+int ptr_device_function(ptr_ctx* c, const char* name, const uint32_t* in, uint32_t in_words, uint32_t* out, uint32_t out_words,
+                        uint32_t count) {
+    if (!c) return PTR_E_INVALID;
+    if (!name || !in || !out) return fail(c, PTR_E_INVALID, "ptr_device_function: null argument");
+    uint32_t want_in = 0, want_out = 0;
+    const int fn = ptr::unit_function_lookup(name, &want_in, &want_out);
+    if (fn < 0) return fail(c, PTR_E_UNSUPPORTED, "ptr_device_function: unknown function '%s'", name);
+    if (in_words != want_in || out_words != want_out)
+        return fail(c, PTR_E_INVALID, "ptr_device_function: '%s' takes %u words and returns %u, got %u and %u", name, want_in, want_out, in_words, out_words);
+    if (count == 0) return PTR_OK;
+    if (count > (1u << 24)) return fail(c, PTR_E_RANGE, "ptr_device_function: at most %u records per call", 1u << 24);
+    int rc = bind_device(c); if (rc) return rc;
+    uint32_t *d_in = nullptr, *d_out = nullptr;
+    const size_t in_bytes = (size_t)count * in_words * 4, out_bytes = (size_t)count * out_words * 4;
+    PTR_HIP_CHECK(c, hipMalloc((void**)&d_in, in_bytes));
+    hipError_t e = hipMalloc((void**)&d_out, out_bytes);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_in, in, in_bytes, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(d_out, 0, out_bytes, c->stream);
+    if (e == hipSuccess) e = ptr::launch_unit_function(c->stream, fn, d_in, in_words, d_out, out_words, count);
+    if (e == hipSuccess) e = hipMemcpyAsync(out, d_out, out_bytes, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(d_in);
+    if (d_out) (void)hipFree(d_out);
+    if (e != hipSuccess) return fail(c, PTR_E_HIP, "ptr_device_function: %s", hipGetErrorString(e));
+    return PTR_OK;
+}
+
 int ptr_image_index(ptr_ctx* c, ptr_handle h, uint32_t* index) {
     if (!c || !index) return PTR_E_INVALID;
     if (!find_image(c, h)) return fail(c, PTR_E_INVALID, "ptr_image_index: unknown image %u", h);

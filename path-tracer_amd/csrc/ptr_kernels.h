@@ -55,4 +55,8 @@ hipError_t launch_wf_shade(hipStream_t s, const SceneView& sv, const WavefrontSc
                            uint32_t min_bounce, uint32_t domain_w, uint32_t domain_h);
 hipError_t launch_wf_accumulate(hipStream_t s, const SceneView& sv, const WavefrontScratch& w, uint32_t domain_w, uint32_t domain_h);
 
+// Per-function test kernel (ptr_kernels_unit.hip): index of `name` (< 0 if unknown) with its record sizes in 32-bit words.
+int unit_function_lookup(const char* name, uint32_t* in_words, uint32_t* out_words);
+hipError_t launch_unit_function(hipStream_t s, int fn, const uint32_t* in, uint32_t in_words, uint32_t* out, uint32_t out_words, uint32_t count);
+
 }  // namespace ptr

@@ -69,6 +69,7 @@ def lib():
         "ptr_profile_enable": [vp, C.c_int],
         "ptr_profile_read": [vp, C.c_char_p, P(u64), P(C.c_double), C.c_int],
         "ptr_profile_names": [vp, C.c_char_p, sz],
+        "ptr_device_function": [vp, C.c_char_p, vp, u32, vp, u32, u32],
     }
     for name, args in sigs.items():
         fn = getattr(L, name)
@@ -85,7 +86,7 @@ ABI_SYMBOLS = ["ptr_ctx_create", "ptr_ctx_destroy", "ptr_ctx_set_stream", "ptr_l
                "ptr_image_create", "ptr_image_wrap", "ptr_image_destroy", "ptr_image_upload", "ptr_image_read",
                "ptr_image_index", "ptr_sampler_index", "ptr_image_address", "ptr_bvh_bind_flat", "ptr_dispatch",
                "ptr_set_partition", "ptr_set_sample_partition", "ptr_set_option", "ptr_set_capture", "ptr_stats_enable", "ptr_stats_read", "ptr_profile_enable",
-               "ptr_profile_read", "ptr_profile_names"]
+               "ptr_profile_read", "ptr_profile_names", "ptr_device_function"]
 
 
 class Context:
@@ -171,6 +172,15 @@ class Context:
             ms = C.c_double()
             self._check(self._L.ptr_profile_read(self.handle, name.encode(), C.byref(n), C.byref(ms), 1 if reset else 0))
             out[name] = dict(launches=int(n.value), total_ms=float(ms.value))
+        return out
+
+    def device_function(self, name, records, out_words):
+        """Evaluates one device function on `records` ((count, in_words) array of 32-bit words: float32 or uint32,
+        or a structured mix viewed as uint32); returns a (count, out_words) uint32 array (view as float32 as needed)."""
+        a = np.ascontiguousarray(records)
+        assert a.ndim == 2 and a.dtype.itemsize == 4
+        out = np.zeros((a.shape[0], out_words), np.uint32)
+        self._check(self._L.ptr_device_function(self.handle, name.encode(), a.ctypes.data, a.shape[1], out.ctypes.data, out_words, a.shape[0]))
         return out
 
     def bind_flat(self, node_buffer, flat_buffer):
