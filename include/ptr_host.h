@@ -38,6 +38,29 @@ void ptrh_free(void* p);
 void ptrh_camera(const float pos[3], const float target[3], float v_fov, float aspect, float aperture, float focus_dist,
                  const float* ops, int32_t n_ops, void* out);
 
+/* ---- glTF -> flat scene arrays: gltf::gltf(path) + the flattening loop of scene::scene -- reference:
+ * src/gltf.cpp:14-195, src/mesh.cpp:5-37, src/scene.cpp:84-176.  *scene_out is an opaque flat scene; free it with
+ * ptrh_scene_free.  apply_transforms 0 = node transforms ignored (what the reference does), 1 = applied. */
+int32_t ptrh_gltf_load(const char* path, int32_t apply_transforms, void** scene_out);
+/* The same flat scene from a .ptrscene file (the headless driver's native container). */
+int32_t ptrh_scene_load(const char* path, void** scene_out);
+/* counts = { index words (3 per triangle), vertices, material records, textures } */
+int32_t ptrh_scene_counts(const void* scene, uint64_t counts[4]);
+/* Copies the arrays out (any pointer may be NULL): indices u32[counts[0]] (24-bit vertex id | one byte of the
+ * material id, src/scene.cpp:140-142), positions/normals f32[3 * vertices], uvs f32[2 * vertices], materials
+ * counts[2] records of 32 bytes { f32 base_color[4]; u32 albedo_texture, mr_texture (1-based, 0 = none);
+ * f32 metalness, roughness }. */
+int32_t ptrh_scene_arrays(const void* scene, uint32_t* indices, float* positions, float* normals, float* uvs, void* materials);
+/* Texture `index` (0-based): size and, if rgba != NULL, its width*height*4 RGBA8 texels. */
+int32_t ptrh_scene_texture(const void* scene, uint32_t index, uint32_t* width, uint32_t* height, uint8_t* rgba);
+void ptrh_scene_free(void* scene);
+
+/* PNG / JPEG file image -> RGBA8 (what stbi_load(path, &w, &h, &channels, 4) returns, src/gltf.cpp:103-112);
+ * *rgba_out is malloc'ed, free with ptrh_free. */
+int32_t ptrh_image_decode(const uint8_t* bytes, uint64_t size, int32_t* width, int32_t* height, int32_t* channels, uint8_t** rgba_out);
+/* Parses a JSON text and re-serialises it compactly (malloc'ed, free with ptrh_free): the reader's test hook. */
+int32_t ptrh_json_dump(const char* text, uint64_t size, char** out);
+
 #ifdef __cplusplus
 }
 #endif

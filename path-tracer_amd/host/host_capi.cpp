@@ -8,6 +8,10 @@
 
 #include "bvh.hpp"
 #include "camera.hpp"
+#include "gltf.hpp"
+#include "image.hpp"
+#include "json.hpp"
+#include "scene_source.hpp"
 
 namespace {
 thread_local std::string g_last_error;
@@ -97,6 +101,91 @@ void ptrh_camera(const float pos[3], const float target[3], float v_fov, float a
         }
     }
     std::memcpy(out, &cam, sizeof(camera));
+}
+
+// ---- glTF -> flat scene arrays ---------------------------------------------------------------------------
+int32_t ptrh_gltf_load(const char* path, int32_t apply_transforms, void** scene_out) {
+    try {
+        if (!path || !scene_out) { g_last_error = "ptrh_gltf_load: null argument"; return -1; }
+        const gltf model{ std::string(path) };
+        *scene_out = new scene_source(model.flatten(apply_transforms != 0));
+        return 0;
+    } catch (const std::exception& e) {
+        g_last_error = e.what();
+        return -1;
+    }
+}
+
+int32_t ptrh_scene_load(const char* path, void** scene_out) {
+    try {
+        if (!path || !scene_out) { g_last_error = "ptrh_scene_load: null argument"; return -1; }
+        *scene_out = new scene_source(scene_source::load(path));
+        return 0;
+    } catch (const std::exception& e) {
+        g_last_error = e.what();
+        return -1;
+    }
+}
+
+int32_t ptrh_scene_counts(const void* scene, uint64_t counts[4]) {
+    if (!scene || !counts) { g_last_error = "ptrh_scene_counts: null argument"; return -1; }
+    const scene_source* s = (const scene_source*)scene;
+    counts[0] = s->indices.size(); counts[1] = s->positions.size() / 3; counts[2] = s->materials.size(); counts[3] = s->textures.size();
+    return 0;
+}
+
+int32_t ptrh_scene_arrays(const void* scene, uint32_t* indices, float* positions, float* normals, float* uvs, void* materials) {
+    if (!scene) { g_last_error = "ptrh_scene_arrays: null scene"; return -1; }
+    const scene_source* s = (const scene_source*)scene;
+    static_assert(sizeof(scene_source::source_material) == 32, "material record handed to C callers is 32 bytes");
+    if (indices) std::memcpy(indices, s->indices.data(), s->indices.size() * 4);
+    if (positions) std::memcpy(positions, s->positions.data(), s->positions.size() * 4);
+    if (normals) std::memcpy(normals, s->normals.data(), s->normals.size() * 4);
+    if (uvs) std::memcpy(uvs, s->uvs.data(), s->uvs.size() * 4);
+    if (materials) std::memcpy(materials, s->materials.data(), s->materials.size() * sizeof(scene_source::source_material));
+    return 0;
+}
+
+int32_t ptrh_scene_texture(const void* scene, uint32_t index, uint32_t* width, uint32_t* height, uint8_t* rgba) {
+    if (!scene) { g_last_error = "ptrh_scene_texture: null scene"; return -1; }
+    const scene_source* s = (const scene_source*)scene;
+    if (index >= s->textures.size()) { g_last_error = "ptrh_scene_texture: index out of range"; return -1; }
+    const auto& t = s->textures[index];
+    if (width) *width = t.width;
+    if (height) *height = t.height;
+    if (rgba) std::memcpy(rgba, t.rgba.data(), t.rgba.size());
+    return 0;
+}
+
+void ptrh_scene_free(void* scene) { delete (scene_source*)scene; }
+
+int32_t ptrh_image_decode(const uint8_t* bytes, uint64_t size, int32_t* width, int32_t* height, int32_t* channels, uint8_t** rgba_out) {
+    try {
+        if (!bytes || !width || !height || !channels || !rgba_out) { g_last_error = "ptrh_image_decode: null argument"; return -1; }
+        const raw_image im = decode_image(bytes, (size_t)size);
+        *width = im.width; *height = im.height; *channels = im.channels;
+        *rgba_out = (uint8_t*)std::malloc(im.data.size() ? im.data.size() : 1);
+        if (!*rgba_out) { g_last_error = "ptrh_image_decode: out of memory"; return -1; }
+        std::memcpy(*rgba_out, im.data.data(), im.data.size());
+        return 0;
+    } catch (const std::exception& e) {
+        g_last_error = e.what();
+        return -1;
+    }
+}
+
+int32_t ptrh_json_dump(const char* text, uint64_t size, char** out) {
+    try {
+        if (!text || !out) { g_last_error = "ptrh_json_dump: null argument"; return -1; }
+        const std::string d = json::parse(std::string(text, (size_t)size)).dump();
+        *out = (char*)std::malloc(d.size() + 1);
+        if (!*out) { g_last_error = "ptrh_json_dump: out of memory"; return -1; }
+        std::memcpy(*out, d.c_str(), d.size() + 1);
+        return 0;
+    } catch (const std::exception& e) {
+        g_last_error = e.what();
+        return -1;
+    }
 }
 
 }  // extern "C"

@@ -11,24 +11,11 @@
 
 #include "camera.hpp"
 #include "material.hpp"
+#include "scene_source.hpp"
 
 class Buffer;
 class Texture;
 class Sampler;
-
-// Flat scene arrays, i.e. what src/scene.cpp:84-176 produces from the glTF node tree.
-struct scene_source {
-    std::vector<uint32_t> indices;     // 3 per triangle: 24-bit vertex index | one byte of the 24-bit material id
-    std::vector<float> positions;      // 3 per vertex
-    std::vector<float> normals;        // 3 per vertex
-    std::vector<float> uvs;            // 2 per vertex
-    struct source_material { float base_color[4]; uint32_t albedo_texture, mr_texture; float metalness, roughness; };
-    std::vector<source_material> materials;  // texture numbers are 1-based indices into `textures`, 0 = none
-    struct source_texture { uint32_t width, height; std::vector<uint8_t> rgba; };
-    std::vector<source_texture> textures;
-
-    static scene_source load(const std::string& path);  // .ptrscene file, see scene.cpp
-};
 
 class scene {
 public:

@@ -1,0 +1,23 @@
+// The flat scene arrays the kernels read, before upload: what src/scene.cpp:84-176 produces from a glTF node tree.
+// Filled by the glTF loader (gltf::flatten) or read from a .ptrscene file.  No GPU dependency.
+#ifndef PTR_SCENE_SOURCE_HPP_
+#define PTR_SCENE_SOURCE_HPP_
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+struct scene_source {
+    std::vector<uint32_t> indices;     // 3 per triangle: 24-bit vertex index | one byte of the 24-bit material id
+    std::vector<float> positions;      // 3 per vertex
+    std::vector<float> normals;        // 3 per vertex
+    std::vector<float> uvs;            // 2 per vertex
+    struct source_material { float base_color[4]; uint32_t albedo_texture, mr_texture; float metalness, roughness; };
+    std::vector<source_material> materials;  // texture numbers are 1-based indices into `textures`, 0 = none
+    struct source_texture { uint32_t width, height; std::vector<uint8_t> rgba; };
+    std::vector<source_texture> textures;
+
+    static scene_source load(const std::string& path);  // .ptrscene file, see scene_source.cpp
+};
+
+#endif  // PTR_SCENE_SOURCE_HPP_

@@ -1,5 +1,6 @@
 """ctypes binding of host/libptr_host.so: the scene-preparation code (BVH builder + GPU flattener, camera)."""
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -21,6 +22,15 @@ def lib():
         L.ptrh_free.argtypes = [C.c_void_p]
         L.ptrh_camera.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p,
                                   C.c_int32, C.c_void_p]
+        vp = C.c_void_p
+        L.ptrh_gltf_load.argtypes = [C.c_char_p, C.c_int32, C.POINTER(vp)]
+        L.ptrh_scene_load.argtypes = [C.c_char_p, C.POINTER(vp)]
+        L.ptrh_scene_counts.argtypes = [vp, C.POINTER(C.c_uint64)]
+        L.ptrh_scene_arrays.argtypes = [vp, vp, vp, vp, vp, vp]
+        L.ptrh_scene_texture.argtypes = [vp, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), vp]
+        L.ptrh_scene_free.argtypes = [vp]
+        L.ptrh_image_decode.argtypes = [vp, C.c_uint64, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(vp)]
+        L.ptrh_json_dump.argtypes = [C.c_char_p, C.c_uint64, C.POINTER(vp)]
         _lib = L
     return _lib
 
@@ -89,3 +99,91 @@ def camera(pos, target, v_fov, aspect, aperture, focus, ops=()):
     lib().ptrh_camera(pos.ctypes.data, tgt.ctypes.data, v_fov, aspect, aperture, focus, o.ctypes.data, o.shape[0],
                       out.ctypes.data)
     return out
+
+
+HOST_SYMBOLS = ["ptrh_last_error", "ptrh_sizes", "ptrh_bvh_build", "ptrh_bvh_visit_ranks", "ptrh_bvh_flatten", "ptrh_free", "ptrh_camera",
+                "ptrh_gltf_load", "ptrh_scene_load", "ptrh_scene_counts", "ptrh_scene_arrays", "ptrh_scene_texture", "ptrh_scene_free",
+                "ptrh_image_decode", "ptrh_json_dump"]
+
+# 32-byte material record of a flat scene before upload (texture numbers are 1-based, 0 = none)
+SOURCE_MATERIAL_DTYPE = np.dtype([("base_color", np.float32, 4), ("albedo_tex", np.uint32), ("mr_tex", np.uint32),
+                                  ("metalness", np.float32), ("roughness", np.float32)])
+
+
+def _scene_to_dict(handle):
+    L = lib()
+    try:
+        counts = (C.c_uint64 * 4)()
+        if L.ptrh_scene_counts(handle, counts) != 0:
+            raise HostError(L.ptrh_last_error().decode())
+        n_idx, n_vtx, n_mat, n_tex = (int(c) for c in counts)
+        out = dict(indices=np.zeros(n_idx, np.uint32), positions=np.zeros(n_vtx * 3, np.float32), normals=np.zeros(n_vtx * 3, np.float32),
+                   uvs=np.zeros(n_vtx * 2, np.float32))
+        mats = np.zeros(n_mat, SOURCE_MATERIAL_DTYPE)
+        if L.ptrh_scene_arrays(handle, out["indices"].ctypes.data, out["positions"].ctypes.data, out["normals"].ctypes.data,
+                               out["uvs"].ctypes.data, mats.ctypes.data) != 0:
+            raise HostError(L.ptrh_last_error().decode())
+        # the 48-byte device record layout the rest of the Python tooling uses (sampler 1 wherever a texture is named)
+        from .scenes import MATERIAL_DTYPE
+        full = np.zeros(n_mat, MATERIAL_DTYPE)
+        full["base_color"] = mats["base_color"]
+        full["albedo_tex"] = mats["albedo_tex"]; full["albedo_sampler"] = (mats["albedo_tex"] != 0).astype(np.uint32)
+        full["mr_tex"] = mats["mr_tex"]; full["mr_sampler"] = (mats["mr_tex"] != 0).astype(np.uint32)
+        full["metalness"] = mats["metalness"]; full["roughness"] = mats["roughness"]
+        out["materials"] = full
+        textures = [None]
+        for i in range(n_tex):
+            w, h = C.c_uint32(), C.c_uint32()
+            L.ptrh_scene_texture(handle, i, C.byref(w), C.byref(h), None)
+            t = np.zeros((h.value, w.value, 4), np.uint8)
+            if L.ptrh_scene_texture(handle, i, None, None, t.ctypes.data) != 0:
+                raise HostError(L.ptrh_last_error().decode())
+            textures.append(t)
+        out["textures"] = textures
+        vid = out["indices"] & np.uint32(0x00FFFFFF)
+        out["triangles"] = np.ascontiguousarray(out["positions"].reshape(-1, 3)[vid].reshape(-1, 9))
+        out["primitive_count"] = n_mat
+        return out
+    finally:
+        L.ptrh_scene_free(handle)
+
+
+def gltf_load(path, apply_transforms=False):
+    """gltf(path).flatten(): the flat scene arrays (same dict layout as scenes.generate, without a camera)."""
+    h = C.c_void_p()
+    if lib().ptrh_gltf_load(os.fsencode(path), 1 if apply_transforms else 0, C.byref(h)) != 0:
+        raise HostError(lib().ptrh_last_error().decode())
+    return _scene_to_dict(h)
+
+
+def ptrscene_load(path):
+    h = C.c_void_p()
+    if lib().ptrh_scene_load(os.fsencode(path), C.byref(h)) != 0:
+        raise HostError(lib().ptrh_last_error().decode())
+    return _scene_to_dict(h)
+
+
+def image_decode(data):
+    """PNG / JPEG bytes -> ((h, w, 4) uint8 RGBA, channels stored in the file)."""
+    buf = np.frombuffer(bytes(data), np.uint8)
+    w, h, ch = C.c_int32(), C.c_int32(), C.c_int32()
+    out = C.c_void_p()
+    if lib().ptrh_image_decode(buf.ctypes.data, buf.size, C.byref(w), C.byref(h), C.byref(ch), C.byref(out)) != 0:
+        raise HostError(lib().ptrh_last_error().decode())
+    try:
+        img = np.ctypeslib.as_array(C.cast(out, C.POINTER(C.c_uint8)), shape=(h.value, w.value, 4)).copy()
+    finally:
+        lib().ptrh_free(out)
+    return img, ch.value
+
+
+def json_dump(text):
+    """Parses `text` with the host's JSON reader and returns its compact re-serialisation."""
+    raw = text.encode() if isinstance(text, str) else bytes(text)
+    out = C.c_void_p()
+    if lib().ptrh_json_dump(raw, len(raw), C.byref(out)) != 0:
+        raise HostError(lib().ptrh_last_error().decode())
+    try:
+        return C.string_at(out).decode()
+    finally:
+        lib().ptrh_free(out)

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 from common import make_bundle, oracle_frames
-from path_tracer_amd import paths, scenes
+from path_tracer_amd import gltf_io, paths, scenes
 
 pytestmark = pytest.mark.gpu
 HEADLESS = os.path.join(paths.HOST, "ptr_headless")
@@ -44,6 +44,24 @@ def test_headless_driver_matches_oracle(tmp_path, pipeline, use_flat):
     assert r.returncode == 0, r.stderr
     head = open(ppm).read().split()[:4]
     assert head == ["P3", str(W), str(H), "255"]
+
+
+@pytest.mark.parametrize("container", ["gltf", "glb"])
+def test_headless_driver_renders_a_gltf_file_like_the_oracle(tmp_path, container):
+    """glTF file -> gltf loader -> flattening -> scene -> kernels: the image equals the oracle's on the arrays the file was written from."""
+    W, H, SPP = 72, 40, 2
+    b = make_bundle("atrium", 3000, W, H, max_bounce=4)
+    scene_file = gltf_io.save_gltf(b, str(tmp_path), "atrium", container=container)
+    out_file = str(tmp_path / "out.pfm")
+    c = b["camera"]
+    cmd = [HEADLESS, "--scene", scene_file, "--width", str(W), "--height", str(H), "--spp", str(SPP), "--max-bounce", "4",
+           "--out", out_file, "--pos", *map(str, c["pos"]), "--target", *map(str, c["target"]),
+           "--fov", str(c["v_fov"]), "--aperture", str(c["aperture"]), "--focus", str(c["focus"])]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    ref, _, _ = oracle_frames(b, SPP, use_flat=True)
+    img = read_ptrf(out_file)
+    assert np.array_equal(img, ref), f"{int((np.abs(img - ref).max(axis=2) > 0).sum())} pixels differ\n{r.stderr}"
 
 
 def test_headless_reports_errors():
