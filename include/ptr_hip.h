@@ -106,7 +106,12 @@ int ptr_set_sample_partition(ptr_ctx* ctx, uint32_t rank, uint32_t world);
  *      "extend.leaf_all"       1 (default): a leaf turn tests the lane's whole leaf; 0: one triangle per turn
  *      "extend.leaf_weight"    1, 2 (default), 4: how strongly lanes waiting at a leaf outvote lanes waiting at an
  *                              inner node when the wave picks the step kind of its next iteration
- *      "extend.blocks_per_cu"  persistent grid size of the traversal kernel, 1..8 blocks of 256 threads per CU (default 8) */
+ *      "extend.blocks_per_cu"  persistent grid size of the traversal kernel, 1..8 blocks of 256 threads per CU (default 8)
+ *      "shade.pregather"       1 (default): the wavefront shade step reads one 80-byte record per hit triangle (vertex
+ *                              normals, uvs, material id, geometry normal) that the library gathers once from the index /
+ *                              positions / normals / uvs buffers of the dispatch and re-gathers after any ptr_buffer_write
+ *                              to them (80 bytes of device memory per triangle); 0: gather from the four arrays per hit,
+ *                              as the shader does (ray.h:20-64).  The results are identical. */
 int ptr_set_option(ptr_ctx* ctx, const char* key, int value);
 
 /* ---- instrumentation (no counterpart in the reference) ---- */

@@ -24,6 +24,7 @@ struct BufferRec {
     ptr_handle flat = 0;  // flattened-layout buffer bound to this (threaded node) buffer
     std::vector<uint8_t> shadow;
     bool flat_view_valid = false;  // this buffer holds a flattened layout whose header was parsed
+    uint64_t generation = 0;       // context-wide write counter at this buffer's creation / last write
     ptr::FlatView flat_view{};
 };
 struct ImageRec {
@@ -71,6 +72,14 @@ struct ptr_ctx {
     int opt_extend_leaf_weight = 2; // leaf lanes count this many times when a traversal wave picks its next step kind
     int opt_extend_refill = 16;     // idle lanes that trigger a refill of the traversal wave (8, 16, 32, 48, 64)
     int opt_extend_blocks_per_cu = 8;
+    int opt_shade_pregather = 1;    // wavefront shade reads per-triangle records gathered once per scene
+    // the records, and what they were built from: addresses + write generations of indices / positions / normals / uvs
+    void* shade_records = nullptr;
+    size_t shade_records_bytes = 0;
+    uint32_t shade_record_count = 0;
+    uint64_t shade_key[8] = {};
+    bool shade_key_valid = false;
+    uint64_t write_epoch = 0;       // bumped by every buffer creation and write
     // small host->device writes (the per-frame 160-byte metadata) go through a ring of pinned slots so that
     // Buffer::write returns without draining the stream
     static constexpr int kStageSlots = 32;
@@ -231,6 +240,53 @@ int check_storage_image(ptr_ctx* c, uint32_t index, const char* what) {
     return PTR_OK;
 }
 
+// Per-triangle shading records of the wavefront shade step: (re)built when the index / positions / normals / uvs
+// addresses of the dispatch, or the contents of the buffers behind them, differ from what the records were built
+// from.  On success sv names the records; with the option off, or an empty index buffer, sv keeps the gather path.
+int ensure_shade_records(ptr_ctx* c, const uint64_t addr[7], const ptr_handle handles[7], ptr::SceneView* sv) {
+    sv->shade_records = nullptr;
+    sv->shade_record_count = 0;
+    if (!c->opt_shade_pregather) return PTR_OK;
+    auto bytes_from = [&](int i) {
+        const BufferRec& b = c->buffers[handles[i]];
+        return (uint64_t)(uintptr_t)b.ptr + b.size - addr[i];
+    };
+    const uint64_t tris = bytes_from(2) / 12u;
+    uint64_t vertices = bytes_from(3) / 12u;
+    if (bytes_from(4) / 12u < vertices) vertices = bytes_from(4) / 12u;
+    if (bytes_from(5) / 8u < vertices) vertices = bytes_from(5) / 8u;
+    if (tris == 0 || vertices == 0 || tris > 0x7fffffffull) return PTR_OK;
+    if (vertices > (1u << 24)) vertices = 1u << 24;  // the packed index words hold 24-bit vertex ids
+    uint64_t key[8];
+    for (int i = 0; i < 4; i++) { key[i] = addr[2 + i]; key[4 + i] = c->buffers[handles[2 + i]].generation; }
+    if (c->shade_key_valid && c->shade_record_count == tris && !memcmp(key, c->shade_key, sizeof key)) {
+        sv->shade_records = (const float4*)c->shade_records;
+        sv->shade_record_count = c->shade_record_count;
+        return PTR_OK;
+    }
+    const size_t need = (size_t)tris * ptr::kShadeRecordVec4 * sizeof(float4);
+    c->shade_key_valid = false;
+    if (need != c->shade_records_bytes) {
+        if (c->shade_records) {
+            PTR_HIP_CHECK(c, hipStreamSynchronize(c->stream));  // frames in flight may still read the old records
+            PTR_HIP_CHECK(c, hipFree(c->shade_records));
+            c->shade_records = nullptr; c->shade_records_bytes = 0;
+        }
+        PTR_HIP_CHECK(c, hipMalloc(&c->shade_records, need));
+        c->shade_records_bytes = need;
+    }
+    {
+        ScopedProfile prof(c, "wavefront.build_shade_records");
+        PTR_HIP_CHECK(c, ptr::launch_wf_build_shade_records(c->stream, *sv, (uint32_t)tris, (uint32_t)vertices, (float4*)c->shade_records));
+    }
+    memcpy(c->shade_key, key, sizeof key);
+    c->shade_key_valid = true;
+    c->shade_record_count = (uint32_t)tris;
+    sv->shade_records = (const float4*)c->shade_records;
+    sv->shade_record_count = c->shade_record_count;
+    return PTR_OK;
+}
+
 int dispatch_compute(ptr_ctx* c, const uint8_t constants[64], uint32_t gx, uint32_t gy, int force /*0 auto,1 mega,2 wavefront*/) {
     const ParsedConstants k = parse_constants(constants);
     ptr::SceneMeta meta;
@@ -303,6 +359,7 @@ int dispatch_compute(ptr_ctx* c, const uint8_t constants[64], uint32_t gx, uint3
         flat_buf->flat_view_valid = true;
     }
     const ptr::FlatView fv = flat_buf->flat_view;
+    if ((rc = ensure_shade_records(c, k.addr, handles, &sv))) return rc;
 
     const uint32_t domain_w = gx * 8u < meta.width ? gx * 8u : meta.width;
     const uint32_t domain_h = gy * 8u < meta.height ? gy * 8u : meta.height;
@@ -367,6 +424,7 @@ int ptr_ctx_destroy(ptr_ctx* c) {
     for (auto& b : c->buffers) if (b.alive && b.ptr) (void)hipFree(b.ptr);
     for (auto& im : c->images) if (im.alive && im.owned && im.ptr) (void)hipFree(im.ptr);
     if (c->scratch_block) (void)hipFree(c->scratch_block);
+    if (c->shade_records) (void)hipFree(c->shade_records);
     if (c->d_images) (void)hipFree(c->d_images);
     if (c->d_stats) (void)hipFree(c->d_stats);
     for (auto e : c->stage_done) if (e) (void)hipEventDestroy(e);
@@ -400,6 +458,7 @@ int ptr_buffer_create(ptr_ctx* c, size_t size, ptr_handle* out) {
     BufferRec b;
     PTR_HIP_CHECK(c, hipMalloc(&b.ptr, size));
     b.size = size; b.alive = true;
+    b.generation = ++c->write_epoch;
     if (size <= kShadowLimit) b.shadow.assign(size, 0);
     if (size <= kShadowLimit) PTR_HIP_CHECK(c, hipMemsetAsync(b.ptr, 0, size, c->stream));
     c->buffers.push_back(std::move(b));
@@ -430,6 +489,7 @@ int ptr_buffer_write(ptr_ctx* c, ptr_handle h, const void* data, size_t offset, 
     int rc = bind_device(c); if (rc) return rc;
     if (!b->shadow.empty()) memcpy(b->shadow.data() + offset, data, size);
     b->flat_view_valid = false;
+    b->generation = ++c->write_epoch;
     if (size <= kShadowLimit && c->stage) {
         const int slot = c->stage_next;
         c->stage_next = (slot + 1) % ptr_ctx::kStageSlots;
@@ -671,6 +731,11 @@ int ptr_set_option(ptr_ctx* c, const char* key, int value) {
     if (!strcmp(key, "extend.leaf_all")) {
         if (value != 0 && value != 1) return fail(c, PTR_E_INVALID, "extend.leaf_all: 0 or 1");
         c->opt_extend_leaf_all = value;
+        return PTR_OK;
+    }
+    if (!strcmp(key, "shade.pregather")) {
+        if (value != 0 && value != 1) return fail(c, PTR_E_INVALID, "shade.pregather: 0 or 1");
+        c->opt_shade_pregather = value;
         return PTR_OK;
     }
     if (!strcmp(key, "extend.blocks_per_cu")) {

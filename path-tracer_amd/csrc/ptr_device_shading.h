@@ -54,6 +54,8 @@ struct SceneView {
     unsigned long long* stats; // optional: [rays, nodes, triangles, shaded]
     uint32_t part_rank, part_world, part_stripe_rows;  // tile partition: stripes of rows
     uint32_t sample_rank, sample_world;                 // sample partition: which global samples this GPU draws
+    const float4* shade_records;  // optional: kShadeRecordVec4 float4 per triangle, see ShadeInputs / gather_shade_inputs
+    uint32_t shade_record_count;
 };
 
 struct Ray { f3 origin, dir; float min_t, max_t; };
@@ -251,6 +253,43 @@ PTR_DEV uint32_t pixel_seed(int32_t cx, int32_t cy, uint32_t sample_index) {  //
     return ((uint32_t)cx * 1973u + (uint32_t)cy * 9277u + sample_index * 26699u) | 1u;
 }
 
+// What the shade step needs of the hit triangle (ray.h:32-64, 146): vertex normals, uvs, material id, geometry normal.
+struct ShadeInputs { f3 n0, n1, n2; f2 uv0, uv1, uv2; uint32_t material; f3 geometry_normal; };
+
+// Fetched the shader's way: three index words, then nine scattered vertex records.
+PTR_DEV ShadeInputs gather_shade_inputs(const SceneView& sv, uint32_t tri) {
+    ShadeInputs s;
+    uint32_t i0, i1, i2;
+    decode_triangle(sv, tri, i0, i1, i2, s.material);
+    const f3 p0 = load3(sv.positions, i0), p1 = load3(sv.positions, i1), p2 = load3(sv.positions, i2);
+    s.geometry_normal = normalize(cross(p1 - p0, p2 - p0));
+    s.n0 = load3(sv.normals, i0); s.n1 = load3(sv.normals, i1); s.n2 = load3(sv.normals, i2);
+    s.uv0.x = sv.uvs[i0 * 2u]; s.uv0.y = sv.uvs[i0 * 2u + 1u];
+    s.uv1.x = sv.uvs[i1 * 2u]; s.uv1.y = sv.uvs[i1 * 2u + 1u];
+    s.uv2.x = sv.uvs[i2 * 2u]; s.uv2.y = sv.uvs[i2 * 2u + 1u];
+    return s;
+}
+
+// The same values from one contiguous 80-byte record per triangle (built once per scene from the arrays above by
+// ptr_wf_build_shade_records): 5 wide loads instead of 30 scattered ones.
+constexpr uint32_t kShadeRecordVec4 = 5;
+PTR_DEV void store_shade_record(float4* rec, const ShadeInputs& s) {
+    rec[0] = make_float4(s.n0.x, s.n0.y, s.n0.z, s.n1.x);
+    rec[1] = make_float4(s.n1.y, s.n1.z, s.n2.x, s.n2.y);
+    rec[2] = make_float4(s.n2.z, s.uv0.x, s.uv0.y, s.uv1.x);
+    rec[3] = make_float4(s.uv1.y, s.uv2.x, s.uv2.y, __uint_as_float(s.material));
+    rec[4] = make_float4(s.geometry_normal.x, s.geometry_normal.y, s.geometry_normal.z, 0.0f);
+}
+PTR_DEV ShadeInputs load_shade_record(const float4* rec) {
+    const float4 a = rec[0], b = rec[1], c = rec[2], d = rec[3], e = rec[4];
+    ShadeInputs s;
+    s.n0 = mk3(a.x, a.y, a.z); s.n1 = mk3(a.w, b.x, b.y); s.n2 = mk3(b.z, b.w, c.x);
+    s.uv0.x = c.y; s.uv0.y = c.z; s.uv1.x = c.w; s.uv1.y = d.x; s.uv2.x = d.y; s.uv2.y = d.z;
+    s.material = __float_as_uint(d.w);
+    s.geometry_normal = mk3(e.x, e.y, e.z);
+    return s;
+}
+
 // ---- one iteration of the bounce loop after the closest-hit query: compute.comp:130-241 -----------------
 // Inputs: the ray that was traced, its closest hit, the path state.  Returns true when the path goes on
 // (r holds the next ray), false when it ended with `result` (throughput on a miss, black otherwise).
@@ -260,21 +299,24 @@ PTR_DEV bool shade_bounce(const SceneView& sv, uint32_t bounce, uint32_t min_bou
     result = mk3(0.0f, 0.0f, 0.0f);
 
     const f3 v = -r.dir;
-    uint32_t i0, i1, i2, mat_id;
-    decode_triangle(sv, (uint32_t)hit.prim, i0, i1, i2, mat_id);
     const f3 bary = mk3(1.0f - hit.u - hit.v, hit.u, hit.v);
+    ShadeInputs in;
+    if (sv.shade_records) {
+        if ((uint32_t)hit.prim >= sv.shade_record_count) return false;  // a hit that names no triangle of the index buffer
+        in = load_shade_record(sv.shade_records + (size_t)hit.prim * kShadeRecordVec4);
+    } else {
+        in = gather_shade_inputs(sv, (uint32_t)hit.prim);
+    }
 
     // geometry normal and hit point as hit_triangle / hit_node produce them (ray.h:146,159,191)
-    const f3 p0 = load3(sv.positions, i0), p1 = load3(sv.positions, i1), p2 = load3(sv.positions, i2);
-    f3 geometry_normal = normalize(cross(p1 - p0, p2 - p0));
+    f3 geometry_normal = in.geometry_normal;
     const f3 point = r.origin + r.dir * hit.t;
 
-    const f3 n0 = load3(sv.normals, i0), n1 = load3(sv.normals, i1), n2 = load3(sv.normals, i2);
-    f3 shading_normal = normalize(((n0 * bary.x) + (n1 * bary.y)) + (n2 * bary.z));
-    const float tu = (sv.uvs[i0 * 2u] * bary.x + sv.uvs[i1 * 2u] * bary.y) + sv.uvs[i2 * 2u] * bary.z;
-    const float tv = (sv.uvs[i0 * 2u + 1u] * bary.x + sv.uvs[i1 * 2u + 1u] * bary.y) + sv.uvs[i2 * 2u + 1u] * bary.z;
+    f3 shading_normal = normalize(((in.n0 * bary.x) + (in.n1 * bary.y)) + (in.n2 * bary.z));
+    const float tu = (in.uv0.x * bary.x + in.uv1.x * bary.y) + in.uv2.x * bary.z;
+    const float tv = (in.uv0.y * bary.x + in.uv1.y * bary.y) + in.uv2.y * bary.z;
 
-    const Material mat = sv.materials[mat_id];
+    const Material mat = sv.materials[in.material];
     const f4 albedo = sample_bindless(sv, mat.albedo_tex, tu, tv);
     const f3 diffuse_color = srgb_to_linear(mk3(albedo.x, albedo.y, albedo.z)) * mk3(mat.base_color[0], mat.base_color[1], mat.base_color[2]);
     const f4 mr = sample_bindless(sv, mat.mr_tex, tu, tv);

@@ -53,6 +53,9 @@ hipError_t launch_wf_extend(hipStream_t s, const FlatView& fv, const WavefrontSc
                             int refill, int leaf_weight, int leaf_all, int inner_reps);
 hipError_t launch_wf_shade(hipStream_t s, const SceneView& sv, const WavefrontScratch& w, uint32_t bounce, uint32_t max_bounce,
                            uint32_t min_bounce, uint32_t domain_w, uint32_t domain_h);
+// Fills the per-triangle shading records (kShadeRecordVec4 float4 each) from the index / positions / normals / uvs arrays
+// of `sv`; vertex ids are clamped to [0, vertex_count).
+hipError_t launch_wf_build_shade_records(hipStream_t s, const SceneView& sv, uint32_t triangle_count, uint32_t vertex_count, float4* records);
 hipError_t launch_wf_accumulate(hipStream_t s, const SceneView& sv, const WavefrontScratch& w, uint32_t domain_w, uint32_t domain_h);
 
 // Per-function test kernel (ptr_kernels_unit.hip): index of `name` (< 0 if unknown) with its record sizes in 32-bit words.

@@ -425,6 +425,30 @@ hipError_t launch_wf_shade(hipStream_t s, const SceneView& sv, const WavefrontSc
     return hipGetLastError();
 }
 
+// One lane per triangle: the shade step's inputs gathered once into a contiguous record.
+__global__ __launch_bounds__(256) void ptr_wf_build_shade_records(SceneView sv, uint32_t triangle_count, uint32_t vertex_count, float4* records) {
+    const uint32_t tri = blockIdx.x * 256u + threadIdx.x;
+    if (tri >= triangle_count) return;
+    ShadeInputs in;
+    uint32_t i0, i1, i2;
+    decode_triangle(sv, tri, i0, i1, i2, in.material);
+    const uint32_t last = vertex_count - 1u;
+    i0 = i0 < last ? i0 : last; i1 = i1 < last ? i1 : last; i2 = i2 < last ? i2 : last;
+    const f3 p0 = load3(sv.positions, i0), p1 = load3(sv.positions, i1), p2 = load3(sv.positions, i2);
+    in.geometry_normal = normalize(cross(p1 - p0, p2 - p0));
+    in.n0 = load3(sv.normals, i0); in.n1 = load3(sv.normals, i1); in.n2 = load3(sv.normals, i2);
+    in.uv0.x = sv.uvs[i0 * 2u]; in.uv0.y = sv.uvs[i0 * 2u + 1u];
+    in.uv1.x = sv.uvs[i1 * 2u]; in.uv1.y = sv.uvs[i1 * 2u + 1u];
+    in.uv2.x = sv.uvs[i2 * 2u]; in.uv2.y = sv.uvs[i2 * 2u + 1u];
+    store_shade_record(records + (size_t)tri * kShadeRecordVec4, in);
+}
+
+hipError_t launch_wf_build_shade_records(hipStream_t s, const SceneView& sv, uint32_t triangle_count, uint32_t vertex_count, float4* records) {
+    if (triangle_count == 0 || vertex_count == 0) return hipSuccess;
+    hipLaunchKernelGGL(ptr_wf_build_shade_records, dim3((triangle_count + 255u) / 256u), dim3(256), 0, s, sv, triangle_count, vertex_count, records);
+    return hipGetLastError();
+}
+
 hipError_t launch_wf_accumulate(hipStream_t s, const SceneView& sv, const WavefrontScratch& w, uint32_t domain_w, uint32_t domain_h) {
     uint32_t tiles_x;
     const uint32_t blocks = tile_blocks(domain_w, domain_h, tiles_x);

@@ -63,6 +63,34 @@ def test_wavefront_matches_the_reference_order_traversal_up_to_declared_ties(ctx
     assert np.array_equal(cap[1][..., 0][same], aov[1][..., 0][same])
 
 
+def test_pregathered_shading_records_change_nothing_and_follow_buffer_writes(ctx):
+    """The wavefront shade step reads per-triangle records gathered once from the index / normal / uv / position buffers:
+    same frames with the records on or off, and a later Buffer::write to one of the sources is picked up."""
+    b = make_bundle("atrium", 4000, 80, 48, max_bounce=4)
+    img_on, gs, _, _ = gpu_frames(ctx, b, 2, "compute.wavefront")
+    ctx.set_option("shade.pregather", 0)
+    try:
+        img_off, _, _, _ = gpu_frames(ctx, b, 2, "compute.wavefront", gpu_scene=gs)
+    finally:
+        ctx.set_option("shade.pregather", 1)
+    ref, _, _ = oracle_for(b, gs, 2, use_flat=True)
+    assert_same(img_on, ref, "records on vs oracle")
+    assert_same(img_off, ref, "records off vs oracle")
+
+    # tilt every vertex normal and swap the uv axes, in place, after the records were built
+    n = np.asarray(b["normals"], np.float32).reshape(-1, 3).copy()
+    n = n + np.float32(0.35) * np.roll(n, 1, axis=1)
+    n = (n / np.linalg.norm(n, axis=1, keepdims=True)).astype(np.float32)
+    uv = np.ascontiguousarray(np.asarray(b["uvs"], np.float32).reshape(-1, 2)[:, ::-1])
+    gs.normals_buffer.write(n.reshape(-1))
+    gs.uvs_buffer.write(uv.reshape(-1))
+    b2 = dict(b, normals=n.reshape(-1), uvs=uv.reshape(-1))
+    img2, _, _, _ = gpu_frames(ctx, b2, 2, "compute.wavefront", gpu_scene=gs)
+    ref2, _, _ = oracle_for(b2, gs, 2, use_flat=True)
+    assert not np.array_equal(ref2, ref)
+    assert_same(img2, ref2, "after rewriting normals and uvs")
+
+
 def test_auto_pipeline_picks_wavefront_when_a_flat_layout_is_bound(ctx):
     b = make_bundle("tiny", 0, 48, 32, max_bounce=3)
     img_auto, gs, _, _ = gpu_frames(ctx, b, 2, "compute")
