@@ -84,6 +84,22 @@ def cpu_baseline(args, sc, nodes, flat, meta, gpu_scene, budget_s):
                        f"{rays} rays in {dt:.1f}s, reference-order threaded BVH")
 
 
+def pmc_traffic(kernel, workload):
+    """HBM bytes per launch of `kernel` from the committed counter passes of this same command (profiles/traffic.json,
+    written by scripts/traffic_from_pmc.py): FETCH_SIZE and WRITE_SIZE come from separate rocprofv3 --pmc runs, so
+    they cannot be collected inside this process.  None when the file is missing or was measured on another workload."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        with open(path) as f:
+            t = json.load(f)
+    except (OSError, ValueError):
+        return None, "no profiles/traffic.json"
+    rec = t.get("kernels", {}).get(kernel)
+    if rec is None or t.get("workload") != workload:
+        return None, "profiles/traffic.json holds no counters for this kernel and workload"
+    return rec["bytes_per_launch"], t.get("note", "")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -97,6 +113,8 @@ def main():
     ap.add_argument("--texture-size", type=int, default=512)
     ap.add_argument("--pipeline", default="compute", choices=["compute", "compute.megakernel", "compute.wavefront"])
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline leg (0 = skip)")
+    ap.add_argument("--stream", default="torch", choices=["torch", "own"], help="the context's stream: torch's current stream or its own")
+    ap.add_argument("--frames-in-flight", type=int, default=2, help="consecutive frames overlapped on internal streams (1 = none)")
     args = ap.parse_args()
 
     import torch
@@ -129,7 +147,7 @@ def main():
 
     stream = torch.cuda.Stream()
     with torch.cuda.stream(stream):
-        ctx = hip.Context(local_rank, stream=stream.cuda_stream)
+        ctx = hip.Context(local_rank, stream=stream.cuda_stream if args.stream == "torch" else None)
         gpu = hip.GpuScene(ctx, sc, nodes, flat, meta)
         W, H = args.width, args.height
         img_a = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
@@ -140,6 +158,7 @@ def main():
         loop = hip.FrameLoop(ctx, gpu, W, H, args.pipeline, textures=(tex_a, tex_b))
         if world > 1:
             ctx.set_sample_partition(rank, world)
+        ctx.set_option("frames.in_flight", args.frames_in_flight)
 
         exchange = ctx.create_compute_renderpass()
 
@@ -170,8 +189,10 @@ def main():
         barrier()
         loop.reset()
         img_a.zero_(); img_b.zero_()
+        # live kernel timing inside the timed region: HIP events around the dominant kernel, on the stream it runs on
         ctx.profile_read(reset=True)
-        ctx.profile_enable(True)
+        ctx.set_option("profile.extend_only", 1)
+        ctx.profile_enable(not os.environ.get("PTR_BENCH_NO_LIVE_PROFILE"))
         barrier()
         t0 = time.perf_counter()
         for _ in range(args.steps):
@@ -184,6 +205,19 @@ def main():
         elapsed = time.perf_counter() - t0
         ctx.profile_enable(False)
         prof = ctx.profile_read(reset=True)
+        ctx.set_option("profile.extend_only", 0)
+
+        # per-kernel split of a frame that has the GPU to itself (one frame in flight), outside the timed region
+        loop.reset()
+        ctx.set_option("frames.in_flight", 1)
+        ctx.profile_enable(True)
+        solo_frames = min(args.steps, 10)
+        for _ in range(solo_frames):
+            loop.frame()
+        torch.cuda.synchronize()
+        ctx.profile_enable(False)
+        solo = ctx.profile_read(reset=True)
+        ctx.set_option("frames.in_flight", args.frames_in_flight)
 
         # exact work of the timed frames: re-run the same sample indices with the counting kernel variants
         loop.reset()
@@ -211,23 +245,32 @@ def main():
             node_bytes, tri_bytes = (64, 64) if wavefront else (32, 48)
             algo_bytes = node_bytes * stats["nodes"] + tri_bytes * stats["triangles"]  # this rank's launches
             achieved = algo_bytes / (k["total_ms"] * 1e-3) / 1e9 if k["total_ms"] > 0 else 0.0
+            line_workload = (f"{args.scene} (Bistro-Exterior-class procedural stand-in), {sc['triangles'].shape[0]} triangles, "
+                             f"{W}x{H}, 1 spp per step, max_bounce {args.bounces}, min_bounce 1, dof off")
+            ks = solo.get(dominant, dict(launches=0, total_ms=0.0))
+            solo_bytes = algo_bytes * ks["launches"] / max(1, k["launches"])
+            traffic, traffic_note = pmc_traffic(dominant, line_workload)
             line = {
                 "metric": "Mrays/s", "value": rays_total / elapsed / 1e6, "unit": "Mrays/s",
                 "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
                 "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-                "config": {"workload": f"{args.scene} (Bistro-Exterior-class procedural stand-in), {sc['triangles'].shape[0]} triangles, "
-                                       f"{W}x{H}, 1 spp per step, max_bounce {args.bounces}, min_bounce 1, dof off",
+                "config": {"workload": line_workload,
                            "pipeline": "wavefront over flattened BVH" if wavefront else "megakernel over threaded BVH",
-                           "partition": "samples" if world > 1 else "none",
+                           "partition": "samples" if world > 1 else "none", "frames_in_flight": args.frames_in_flight,
                            "rays_per_step_per_gpu": stats["rays"] / args.steps},
                 "ms_per_frame": elapsed / args.steps * 1e3,
                 "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                             "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                              "launches": k["launches"], "avg_launch_ms": k["total_ms"] / max(1, k["launches"]),
                              "algorithmic_bytes_per_launch": algo_bytes / max(1, k["launches"]),
                              "bytes_per_unit": {"node": node_bytes, "triangle": tri_bytes},
-                             "nodes_per_ray": stats["nodes"] / max(1, stats["rays"]), "triangles_per_ray": stats["triangles"] / max(1, stats["rays"])},
-                "kernels_ms_per_step": {n: v["total_ms"] / args.steps for n, v in sorted(prof.items())},
+                             "nodes_per_ray": stats["nodes"] / max(1, stats["rays"]), "triangles_per_ray": stats["triangles"] / max(1, stats["rays"]),
+                             "traffic_note": traffic_note,
+                             # the same kernel with the GPU to itself (one frame in flight): launches of overlapped frames share the CUs
+                             "solo": {"avg_launch_ms": ks["total_ms"] / max(1, ks["launches"]),
+                                      "achieved": solo_bytes / (ks["total_ms"] * 1e-3) / 1e9 if ks["total_ms"] > 0 else 0.0,
+                                      "frac": (solo_bytes / (ks["total_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS) if ks["total_ms"] > 0 else 0.0}},
+                "kernels_ms_per_step_solo": {n: v["total_ms"] / solo_frames for n, v in sorted(solo.items())},
                 "setup": build_times,
             }
             if world == 1 and args.cpu_seconds > 0:

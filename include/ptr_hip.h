@@ -106,7 +106,17 @@ int ptr_set_sample_partition(ptr_ctx* ctx, uint32_t rank, uint32_t world);
  *      "extend.leaf_all"       1 (default): a leaf turn tests the lane's whole leaf; 0: one triangle per turn
  *      "extend.leaf_weight"    1, 2 (default), 4: how strongly lanes waiting at a leaf outvote lanes waiting at an
  *                              inner node when the wave picks the step kind of its next iteration
- *      "extend.blocks_per_cu"  persistent grid size of the traversal kernel, 1..8 blocks of 256 threads per CU (default 8)
+ *      "extend.blocks_per_cu"  persistent grid size of the traversal kernel, 1..64 blocks of 256 threads per CU (default 7)
+ *      "frames.in_flight"      1..4 (default 2): "compute" dispatches of the wavefront pipeline run on that many internal
+ *                              streams in turn, each with its own scratch, so that the tail of one frame overlaps the
+ *                              start of the next.  The accumulate step (the only one that touches images) is ordered by
+ *                              events after everything enqueued on the context's stream before the dispatch and before
+ *                              everything enqueued after it, so images, reads and ptr_sync behave as with one stream.
+ *                              A write to a buffer a frame in flight still reads waits for that frame first.
+ *                              1 = one stream for everything.  (Measured on MI355X: 2 gives 1.38x the frame rate of 1;
+ *                              3 is slower than 2 because a fourth active hardware queue costs more than it hides.)
+ *      "profile.extend_only"   1: ptr_profile_enable records events around the traversal kernel only (the events between
+ *                              the other kernels cost a few per cent of the frame rate); 0 (default): around every kernel.
  *      "shade.pregather"       1 (default): the wavefront shade step reads one 80-byte record per hit triangle (vertex
  *                              normals, uvs, material id, geometry normal) that the library gathers once from the index /
  *                              positions / normals / uvs buffers of the dispatch and re-gathers after any ptr_buffer_write

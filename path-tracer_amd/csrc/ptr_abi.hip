@@ -62,16 +62,35 @@ struct ptr_ctx {
     unsigned long long* d_stats = nullptr;  // 8 counters
     uint64_t stats_frames = 0;
     bool profile_on = false;
+    int opt_profile_extend_only = 0;  // 1: events around the traversal kernel only (fewer events between the other kernels)
     std::map<std::string, ProfileRec> profile;
     std::vector<hipEvent_t> event_pool;
-    ptr::WavefrontScratch scratch{};
-    void* scratch_block = nullptr;
+    // Frames of the wavefront pipeline run on auxiliary streams, kMaxFrameSlots at most in flight, each with its own
+    // scratch, so that the latency-bound tail of one frame (few rays left in the last bounces, kernel boundaries)
+    // overlaps the start of the next.  Only the accumulate step touches images: it is ordered, by events, after
+    // everything enqueued on the context's stream before the dispatch and before everything enqueued after it, so
+    // images behave as if the whole frame had run on the context's stream.
+    static constexpr int kMaxFrameSlots = 4;
+    struct FrameSlot {
+        hipStream_t stream = nullptr;
+        hipEvent_t ready = nullptr;      // recorded on the context's stream at dispatch: the inputs written before it
+        hipEvent_t images = nullptr;     // recorded on the context's stream at dispatch: the image work enqueued before it
+        hipEvent_t consumed = nullptr;   // recorded on the slot's stream after the frame's accumulate step
+        bool in_flight = false;          // `consumed` has been recorded for a frame of this slot
+        uint64_t synced_epoch = 0;       // value of write_epoch when this slot's stream last waited for the context's stream
+        ptr::WavefrontScratch scratch{};
+        void* scratch_block = nullptr;
+        ptr_handle reads[8] = {};        // buffers the slot's last frame reads (hazard check of later writes)
+    };
+    FrameSlot slots[kMaxFrameSlots];
+    int next_slot = 0;
+    int opt_frames_in_flight = 2;   // 1 = every frame start to end on the context's stream
     int cu_count = 256;
     int opt_extend_inner_reps = 3;  // inner-node steps per inner turn
     int opt_extend_leaf_all = 1;    // 1: a leaf turn tests every triangle of the leaf, 0: one triangle per turn
     int opt_extend_leaf_weight = 2; // leaf lanes count this many times when a traversal wave picks its next step kind
     int opt_extend_refill = 16;     // idle lanes that trigger a refill of the traversal wave (8, 16, 32, 48, 64)
-    int opt_extend_blocks_per_cu = 8;
+    int opt_extend_blocks_per_cu = 7;
     int opt_shade_pregather = 1;    // wavefront shade reads per-triangle records gathered once per scene
     // the records, and what they were built from: addresses + write generations of indices / positions / normals / uvs
     void* shade_records = nullptr;
@@ -80,6 +99,7 @@ struct ptr_ctx {
     uint64_t shade_key[8] = {};
     bool shade_key_valid = false;
     uint64_t write_epoch = 0;       // bumped by every buffer creation and write
+    uint64_t shared_epoch = 0;      // write_epoch of the last change to what every frame reads: textures, image table, shading records
     // small host->device writes (the per-frame 160-byte metadata) go through a ring of pinned slots so that
     // Buffer::write returns without draining the stream
     static constexpr int kStageSlots = 32;
@@ -143,6 +163,7 @@ int upload_image_desc(ptr_ctx* c, ptr_handle h) {
     PTR_HIP_CHECK(c, hipMemcpyAsync(c->d_images + h, &d, sizeof d, hipMemcpyHostToDevice, c->stream));
     // the descriptor lives on the stack: finish the copy before returning
     PTR_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+    c->shared_epoch = ++c->write_epoch;
     return PTR_OK;
 }
 
@@ -155,14 +176,15 @@ hipEvent_t take_event(ptr_ctx* c) {
 }
 struct ScopedProfile {
     ptr_ctx* c; const char* name; hipEvent_t start = nullptr, stop = nullptr;
-    ScopedProfile(ptr_ctx* ctx, const char* n) : c(ctx), name(n) {
-        if (!c->profile_on) return;
+    hipStream_t stream;
+    ScopedProfile(ptr_ctx* ctx, const char* n, hipStream_t on = nullptr) : c(ctx), name(n), stream(on ? on : ctx->stream) {
+        if (!c->profile_on || (c->opt_profile_extend_only && strcmp(n, "wavefront.extend") != 0)) return;
         start = take_event(c); stop = take_event(c);
-        if (start && stop) (void)hipEventRecord(start, c->stream);
+        if (start && stop) (void)hipEventRecord(start, stream);
     }
     ~ScopedProfile() {
         if (!c->profile_on || !start || !stop) return;
-        (void)hipEventRecord(stop, c->stream);
+        (void)hipEventRecord(stop, stream);
         c->profile[name].pending.emplace_back(start, stop);
     }
 };
@@ -181,20 +203,50 @@ void drain_profile(ptr_ctx* c) {
     }
 }
 
-// ---- wavefront scratch ----
-int ensure_scratch(ptr_ctx* c, uint32_t capacity) {
-    if (c->scratch.capacity >= capacity && c->scratch_block &&
-        c->scratch.extend_blocks == (uint32_t)c->cu_count * (uint32_t)c->opt_extend_blocks_per_cu) return PTR_OK;
-    if (c->scratch_block) { PTR_HIP_CHECK(c, hipStreamSynchronize(c->stream)); PTR_HIP_CHECK(c, hipFree(c->scratch_block)); c->scratch_block = nullptr; }
+// ---- frames in flight ----
+// Host-blocking: every frame that was dispatched has finished.  Taken before anything a frame in flight could still be
+// reading is changed or freed.
+int drain_frames(ptr_ctx* c) {
+    for (auto& slot : c->slots)
+        if (slot.stream && slot.in_flight) PTR_HIP_CHECK(c, hipStreamSynchronize(slot.stream));
+    return PTR_OK;
+}
+bool frame_reads(const ptr_ctx* c, ptr_handle h) {
+    for (const auto& slot : c->slots)
+        if (slot.in_flight)
+            for (ptr_handle r : slot.reads) if (r == h && h != 0) return true;
+    return false;
+}
+int ensure_slot(ptr_ctx* c, ptr_ctx::FrameSlot& slot) {
+    if (slot.stream) return PTR_OK;
+    // (Plain priority on purpose: frame streams in the high-priority pool would get hardware queues of their own, but
+    // their event waits on the normal-priority context stream were seen to hang the device.)
+    PTR_HIP_CHECK(c, hipStreamCreateWithFlags(&slot.stream, hipStreamNonBlocking));
+    PTR_HIP_CHECK(c, hipEventCreateWithFlags(&slot.ready, hipEventDisableTiming));
+    PTR_HIP_CHECK(c, hipEventCreateWithFlags(&slot.images, hipEventDisableTiming));
+    PTR_HIP_CHECK(c, hipEventCreateWithFlags(&slot.consumed, hipEventDisableTiming));
+    return PTR_OK;
+}
+
+// ---- wavefront scratch (one per frame slot) ----
+int ensure_scratch(ptr_ctx* c, ptr_ctx::FrameSlot& slot, uint32_t capacity) {
+    if (slot.scratch.capacity >= capacity && slot.scratch_block &&
+        slot.scratch.extend_blocks == (uint32_t)c->cu_count * (uint32_t)c->opt_extend_blocks_per_cu) return PTR_OK;
+    if (slot.scratch_block) {
+        int rc = drain_frames(c); if (rc) return rc;
+        PTR_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+        PTR_HIP_CHECK(c, hipFree(slot.scratch_block));
+        slot.scratch_block = nullptr;
+    }
     const size_t cap = ((size_t)capacity + 255) & ~(size_t)255;
     const uint32_t extend_blocks = (uint32_t)c->cu_count * (uint32_t)c->opt_extend_blocks_per_cu;
     const size_t spill_words = (size_t)extend_blocks * (ptr::kExtendThreads / 64) * ptr::kStackSpill * 64;
     // 2 generations x 3 records of 4 words, hits + samples (4 words each), counters, spill
     const size_t words = cap * (2 * 12 + 8) + 64 + spill_words;
-    PTR_HIP_CHECK(c, hipMalloc(&c->scratch_block, words * 4));
-    uint32_t* p = (uint32_t*)c->scratch_block;
+    PTR_HIP_CHECK(c, hipMalloc(&slot.scratch_block, words * 4));
+    uint32_t* p = (uint32_t*)slot.scratch_block;
     auto take = [&](size_t n) { uint32_t* r = p; p += n; return r; };
-    ptr::WavefrontScratch& s = c->scratch;
+    ptr::WavefrontScratch& s = slot.scratch;
     s.hits = (float4*)take(cap * 4);
     s.samples = (float4*)take(cap * 4);
     for (int g = 0; g < 2; g++) {
@@ -266,6 +318,7 @@ int ensure_shade_records(ptr_ctx* c, const uint64_t addr[7], const ptr_handle ha
     }
     const size_t need = (size_t)tris * ptr::kShadeRecordVec4 * sizeof(float4);
     c->shade_key_valid = false;
+    { int rc = drain_frames(c); if (rc) return rc; }  // frames in flight read the records that are about to change
     if (need != c->shade_records_bytes) {
         if (c->shade_records) {
             PTR_HIP_CHECK(c, hipStreamSynchronize(c->stream));  // frames in flight may still read the old records
@@ -279,6 +332,7 @@ int ensure_shade_records(ptr_ctx* c, const uint64_t addr[7], const ptr_handle ha
         ScopedProfile prof(c, "wavefront.build_shade_records");
         PTR_HIP_CHECK(c, ptr::launch_wf_build_shade_records(c->stream, *sv, (uint32_t)tris, (uint32_t)vertices, (float4*)c->shade_records));
     }
+    c->shared_epoch = ++c->write_epoch;
     memcpy(c->shade_key, key, sizeof key);
     c->shade_key_valid = true;
     c->shade_record_count = (uint32_t)tris;
@@ -305,7 +359,7 @@ int dispatch_compute(ptr_ctx* c, const uint8_t constants[64], uint32_t gx, uint3
     if ((rc = check_storage_image(c, k.accumulation_index, "accumulation"))) return rc;
 
     ptr::SceneView sv{};
-    sv.meta = (const ptr::SceneMeta*)(uintptr_t)k.addr[0];
+    sv.meta = meta;
     sv.nodes = (const ptr::ThreadedNode*)(uintptr_t)k.addr[1];
     sv.indices = (const uint32_t*)(uintptr_t)k.addr[2];
     sv.positions = (const float*)(uintptr_t)k.addr[3];
@@ -364,24 +418,63 @@ int dispatch_compute(ptr_ctx* c, const uint8_t constants[64], uint32_t gx, uint3
     const uint32_t domain_w = gx * 8u < meta.width ? gx * 8u : meta.width;
     const uint32_t domain_h = gy * 8u < meta.height ? gy * 8u : meta.height;
     if (domain_w == 0 || domain_h == 0) return PTR_OK;
+
+    // Which stream traces this frame: one of the auxiliary frame slots, or (counting / capturing runs, or the option
+    // set to 1) the context's own stream after everything in flight has finished.
+    const bool overlap = c->opt_frames_in_flight > 1 && !c->stats_on && !sv.capture;
+    if (c->next_slot >= c->opt_frames_in_flight) c->next_slot = 0;
+    ptr_ctx::FrameSlot& slot = c->slots[overlap ? c->next_slot : 0];
+    if (!overlap && (rc = drain_frames(c))) return rc;
+    if (overlap && (rc = ensure_slot(c, slot))) return rc;
+    hipStream_t ts = overlap ? slot.stream : c->stream;
+
     // queue slots: whole 8x8 tiles of the owned rows (padded by one stripe); samples are indexed by pixel
     const uint32_t padded = ((meta.width + 7u) / 8u) * ((meta.height + 7u) / 8u + c->part_stripe / 8u) * 64u;
-    if ((rc = ensure_scratch(c, padded > meta.width * meta.height ? padded : meta.width * meta.height))) return rc;
-    const ptr::WavefrontScratch& w = c->scratch;
+    if ((rc = ensure_scratch(c, slot, padded > meta.width * meta.height ? padded : meta.width * meta.height))) return rc;
+    const ptr::WavefrontScratch& w = slot.scratch;
 
-    PTR_HIP_CHECK(c, hipMemsetAsync(w.counters, 0, 64 * sizeof(uint32_t), c->stream));
-    if (meta.max_bounce == 0) PTR_HIP_CHECK(c, hipMemsetAsync(w.samples, 0, (size_t)w.capacity * 16, c->stream));
-    { ScopedProfile prof(c, "wavefront.generate"); PTR_HIP_CHECK(c, ptr::launch_wf_generate(c->stream, sv, w, domain_w, domain_h)); }
+    if (overlap) {
+        // the slot's scratch is free once the accumulate step of its previous frame has run
+        if (slot.in_flight) PTR_HIP_CHECK(c, hipStreamWaitEvent(ts, slot.consumed, 0));
+        // Inputs are written on the context's stream.  The slot's stream waits for that stream only when one of this
+        // frame's inputs changed since it last did: the wait also queues the frame behind the accumulate steps of the
+        // frames before it, which is exactly the serialisation the slots exist to avoid.
+        uint64_t newest = c->shared_epoch;
+        for (int i = 1; i < 7; i++) if (c->buffers[handles[i]].generation > newest) newest = c->buffers[handles[i]].generation;
+        if (flat_buf->generation > newest) newest = flat_buf->generation;
+        if (newest > slot.synced_epoch) {
+            PTR_HIP_CHECK(c, hipEventRecord(slot.ready, c->stream));
+            PTR_HIP_CHECK(c, hipStreamWaitEvent(ts, slot.ready, 0));
+            slot.synced_epoch = c->write_epoch;
+        }
+    }
+    PTR_HIP_CHECK(c, hipMemsetAsync(w.counters, 0, 64 * sizeof(uint32_t), ts));
+    if (meta.max_bounce == 0) PTR_HIP_CHECK(c, hipMemsetAsync(w.samples, 0, (size_t)w.capacity * 16, ts));
+    { ScopedProfile prof(c, "wavefront.generate", ts); PTR_HIP_CHECK(c, ptr::launch_wf_generate(ts, sv, w, domain_w, domain_h)); }
     for (uint32_t b = 0; b < meta.max_bounce; b++) {
         if (b + 1 >= ptr::kMaxBounceSlots) {  // recycle the counter slots of a bounce that finished long ago
             const uint32_t s = (b + 1) % ptr::kMaxBounceSlots;
-            PTR_HIP_CHECK(c, hipMemsetAsync(w.counters + s, 0, 4, c->stream));
-            PTR_HIP_CHECK(c, hipMemsetAsync(w.counters + ptr::kMaxBounceSlots + s, 0, 4, c->stream));
+            PTR_HIP_CHECK(c, hipMemsetAsync(w.counters + s, 0, 4, ts));
+            PTR_HIP_CHECK(c, hipMemsetAsync(w.counters + ptr::kMaxBounceSlots + s, 0, 4, ts));
         }
-        { ScopedProfile prof(c, "wavefront.extend"); PTR_HIP_CHECK(c, ptr::launch_wf_extend(c->stream, fv, w, b, sv.stats, c->opt_extend_refill, c->opt_extend_leaf_weight, c->opt_extend_leaf_all, c->opt_extend_inner_reps)); }
-        { ScopedProfile prof(c, "wavefront.shade"); PTR_HIP_CHECK(c, ptr::launch_wf_shade(c->stream, sv, w, b, meta.max_bounce, meta.min_bounce, domain_w, domain_h)); }
+        { ScopedProfile prof(c, "wavefront.extend", ts); PTR_HIP_CHECK(c, ptr::launch_wf_extend(ts, fv, w, b, sv.stats, c->opt_extend_refill, c->opt_extend_leaf_weight, c->opt_extend_leaf_all, c->opt_extend_inner_reps)); }
+        { ScopedProfile prof(c, "wavefront.shade", ts); PTR_HIP_CHECK(c, ptr::launch_wf_shade(ts, sv, w, b, meta.max_bounce, meta.min_bounce, domain_w, domain_h)); }
     }
-    { ScopedProfile prof(c, "wavefront.accumulate"); PTR_HIP_CHECK(c, ptr::launch_wf_accumulate(c->stream, sv, w, domain_w, domain_h)); }
+    if (overlap) {
+        // the context's stream has already been told to wait for the previous frame's accumulate step, so this also
+        // puts the accumulate steps of consecutive frames in dispatch order
+        PTR_HIP_CHECK(c, hipEventRecord(slot.images, c->stream));
+        PTR_HIP_CHECK(c, hipStreamWaitEvent(ts, slot.images, 0));
+    }
+    { ScopedProfile prof(c, "wavefront.accumulate", ts); PTR_HIP_CHECK(c, ptr::launch_wf_accumulate(ts, sv, w, domain_w, domain_h)); }
+    if (overlap) {
+        PTR_HIP_CHECK(c, hipEventRecord(slot.consumed, ts));
+        PTR_HIP_CHECK(c, hipStreamWaitEvent(c->stream, slot.consumed, 0));
+        slot.in_flight = true;
+        for (int i = 0; i < 7; i++) slot.reads[i] = i == 0 ? 0 : handles[i];  // the metadata travels by value
+        slot.reads[7] = bvh_buf->flat;
+        c->next_slot = (c->next_slot + 1) % c->opt_frames_in_flight;
+    }
     return PTR_OK;
 }
 
@@ -418,12 +511,17 @@ int ptr_ctx_create(int device, ptr_ctx** out) {
 int ptr_ctx_destroy(ptr_ctx* c) {
     if (!c) return PTR_E_INVALID;
     (void)hipSetDevice(c->device);
+    for (auto& slot : c->slots) if (slot.stream) (void)hipStreamSynchronize(slot.stream);
     (void)hipStreamSynchronize(c->stream);
     drain_profile(c);
     for (auto e : c->event_pool) (void)hipEventDestroy(e);
+    for (auto& slot : c->slots) {
+        if (slot.scratch_block) (void)hipFree(slot.scratch_block);
+        for (hipEvent_t e : { slot.ready, slot.images, slot.consumed }) if (e) (void)hipEventDestroy(e);
+        if (slot.stream) (void)hipStreamDestroy(slot.stream);
+    }
     for (auto& b : c->buffers) if (b.alive && b.ptr) (void)hipFree(b.ptr);
     for (auto& im : c->images) if (im.alive && im.owned && im.ptr) (void)hipFree(im.ptr);
-    if (c->scratch_block) (void)hipFree(c->scratch_block);
     if (c->shade_records) (void)hipFree(c->shade_records);
     if (c->d_images) (void)hipFree(c->d_images);
     if (c->d_stats) (void)hipFree(c->d_stats);
@@ -437,7 +535,18 @@ int ptr_ctx_destroy(ptr_ctx* c) {
 int ptr_ctx_set_stream(ptr_ctx* c, void* hip_stream) {
     if (!c) return PTR_E_INVALID;
     int rc = bind_device(c); if (rc) return rc;
+    if ((rc = drain_frames(c))) return rc;
     PTR_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+    for (auto& slot : c->slots) slot.in_flight = false;  // their `consumed` events belong to the old stream, which is idle now
+    c->shared_epoch = ++c->write_epoch;
+    // A process has few hardware queues (4 here) and streams that share one run strictly one after the other: the
+    // context's own stream is given up while the caller's stream is in use, so that the frame streams find a free queue.
+    if (hip_stream && c->own_stream) {
+        PTR_HIP_CHECK(c, hipStreamDestroy(c->own_stream));
+        c->own_stream = nullptr;
+    } else if (!hip_stream && !c->own_stream) {
+        PTR_HIP_CHECK(c, hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+    }
     c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
     return PTR_OK;
 }
@@ -447,7 +556,10 @@ const char* ptr_last_error(const ptr_ctx* c) { return c ? c->error.c_str() : g_c
 int ptr_sync(ptr_ctx* c) {
     if (!c) return PTR_E_INVALID;
     int rc = bind_device(c); if (rc) return rc;
+    if ((rc = drain_frames(c))) return rc;
     PTR_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+    // whatever the caller wrote into device memory by other means before this point is ordered before later frames
+    c->shared_epoch = ++c->write_epoch;
     return PTR_OK;
 }
 
@@ -471,6 +583,7 @@ int ptr_buffer_destroy(ptr_ctx* c, ptr_handle h) {
     BufferRec* b = find_buffer(c, h);
     if (!b) return fail(c, PTR_E_INVALID, "ptr_buffer_destroy: unknown buffer %u", h);
     int rc = bind_device(c); if (rc) return rc;
+    if ((rc = drain_frames(c))) return rc;
     PTR_HIP_CHECK(c, hipStreamSynchronize(c->stream));
     PTR_HIP_CHECK(c, hipFree(b->ptr));
     *b = BufferRec();
@@ -487,6 +600,7 @@ int ptr_buffer_write(ptr_ctx* c, ptr_handle h, const void* data, size_t offset, 
     if (offset > b->size || size > b->size - offset) return fail(c, PTR_E_RANGE, "ptr_buffer_write: [%zu, +%zu) outside a %zu-byte buffer", offset, size, b->size);
     if (size == 0) return PTR_OK;
     int rc = bind_device(c); if (rc) return rc;
+    if (frame_reads(c, h) && (rc = drain_frames(c))) return rc;  // a frame in flight still reads this buffer
     if (!b->shadow.empty()) memcpy(b->shadow.data() + offset, data, size);
     b->flat_view_valid = false;
     b->generation = ++c->write_epoch;
@@ -572,6 +686,7 @@ int ptr_image_destroy(ptr_ctx* c, ptr_handle h) {
     ImageRec* im = find_image(c, h);
     if (!im) return fail(c, PTR_E_INVALID, "ptr_image_destroy: unknown image %u", h);
     int rc = bind_device(c); if (rc) return rc;
+    if ((rc = drain_frames(c))) return rc;
     PTR_HIP_CHECK(c, hipStreamSynchronize(c->stream));
     if (im->owned) PTR_HIP_CHECK(c, hipFree(im->ptr));
     *im = ImageRec();
@@ -584,8 +699,10 @@ int ptr_image_upload(ptr_ctx* c, ptr_handle h, const void* texels) {
     if (!im) return fail(c, PTR_E_INVALID, "ptr_image_upload: unknown image %u", h);
     if (!texels) return fail(c, PTR_E_INVALID, "ptr_image_upload: null texels");
     int rc = bind_device(c); if (rc) return rc;
+    if ((rc = drain_frames(c))) return rc;  // frames in flight may sample this image
     PTR_HIP_CHECK(c, hipMemcpyAsync(im->ptr, texels, (size_t)im->w * im->h * texel_size(im->format), hipMemcpyHostToDevice, c->stream));
     PTR_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+    c->shared_epoch = ++c->write_epoch;
     return PTR_OK;
 }
 
@@ -658,6 +775,8 @@ int ptr_bvh_bind_flat(ptr_ctx* c, ptr_handle threaded_nodes, ptr_handle flat) {
         if (!f) return fail(c, PTR_E_INVALID, "ptr_bvh_bind_flat: unknown flat buffer %u", flat);
         if (f->size < 64) return fail(c, PTR_E_INVALID, "ptr_bvh_bind_flat: flat buffer shorter than the 64-byte header");
     }
+    int rc = bind_device(c); if (rc) return rc;
+    if ((rc = drain_frames(c))) return rc;
     b->flat = flat;
     return PTR_OK;
 }
@@ -733,13 +852,25 @@ int ptr_set_option(ptr_ctx* c, const char* key, int value) {
         c->opt_extend_leaf_all = value;
         return PTR_OK;
     }
+    if (!strcmp(key, "profile.extend_only")) {
+        if (value != 0 && value != 1) return fail(c, PTR_E_INVALID, "profile.extend_only: 0 or 1");
+        c->opt_profile_extend_only = value;
+        return PTR_OK;
+    }
+    if (!strcmp(key, "frames.in_flight")) {
+        if (value < 1 || value > ptr_ctx::kMaxFrameSlots) return fail(c, PTR_E_INVALID, "frames.in_flight: 1..%d", ptr_ctx::kMaxFrameSlots);
+        int rc = bind_device(c); if (rc) return rc;
+        if ((rc = drain_frames(c))) return rc;
+        c->opt_frames_in_flight = value;
+        return PTR_OK;
+    }
     if (!strcmp(key, "shade.pregather")) {
         if (value != 0 && value != 1) return fail(c, PTR_E_INVALID, "shade.pregather: 0 or 1");
         c->opt_shade_pregather = value;
         return PTR_OK;
     }
     if (!strcmp(key, "extend.blocks_per_cu")) {
-        if (value < 1 || value > 8) return fail(c, PTR_E_INVALID, "extend.blocks_per_cu: 1..8");
+        if (value < 1 || value > 64) return fail(c, PTR_E_INVALID, "extend.blocks_per_cu: 1..64");
         c->opt_extend_blocks_per_cu = value;
         return PTR_OK;
     }

@@ -40,7 +40,7 @@ struct Capture { int32_t prim0; float t0; int32_t prim1; float t1; };
 
 // Everything one "compute" dispatch needs; built on the host from the 64-byte constant block.
 struct SceneView {
-    const SceneMeta* meta;
+    SceneMeta meta;            // by value: the frame keeps the metadata it was dispatched with, whatever is written next
     const ThreadedNode* nodes;
     const uint32_t* indices;
     const float* positions;

@@ -62,7 +62,7 @@ PTR_DEV uint32_t hit_aabbs(const SceneView& sv, const Ray& r) {
 // compute.comp:264-289
 template <bool STATS>
 __global__ __launch_bounds__(64) void ptr_compute_megakernel(SceneView sv, uint32_t groups_x) {
-    const SceneMeta& m = *sv.meta;
+    const SceneMeta& m = sv.meta;
     const uint32_t group = blockIdx.x;
     const uint32_t lane = threadIdx.x;
     const uint32_t gx = (group % groups_x) * 8u + (lane & 7u);

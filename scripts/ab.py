@@ -26,13 +26,26 @@ def main():
     ap.add_argument("--bounces", type=int, default=4)
     ap.add_argument("--texture-size", type=int, default=512)
     ap.add_argument("--pipeline", default="compute")
+    ap.add_argument("--no-profile", action="store_true", help="time whole frames only (no events between kernels)")
     args = ap.parse_args()
     import bench
     from path_tracer_amd import hip
+    sc = None
+    if os.environ.get("PTR_AB_TORCH"):       # is the frame overlap the same in a process that also runs torch?
+        import torch
+        keep = torch.zeros((args.height, args.width, 4), dtype=torch.float32, device="cuda")
+        if os.environ["PTR_AB_TORCH"] == "stream":
+            keep_stream = torch.cuda.Stream()
+        torch.cuda.synchronize()
     sc, nodes, flat, meta, _ = bench.build_scene(args, 0)
     ctx = hip.Context(0)
     gpu = hip.GpuScene(ctx, sc, nodes, flat, meta)
-    loop = hip.FrameLoop(ctx, gpu, args.width, args.height, args.pipeline)
+    textures = None
+    if os.environ.get("PTR_AB_TORCH") == "wrap":  # the two images live in torch tensors, as in bench.py
+        ia = torch.zeros((args.height, args.width, 4), dtype=torch.float32, device="cuda")
+        ib = torch.zeros_like(ia)
+        textures = (ctx.wrap_2d_texture(ia.data_ptr(), args.width, args.height), ctx.wrap_2d_texture(ib.data_ptr(), args.width, args.height))
+    loop = hip.FrameLoop(ctx, gpu, args.width, args.height, args.pipeline, textures=textures)
     configs = [dict((kv.split("=")[0], int(kv.split("=")[1])) for kv in c.split(",") if kv) for c in args.configs]
     times = [[] for _ in configs]
     kernels = [{} for _ in configs]
@@ -42,7 +55,7 @@ def main():
                 ctx.set_option(k, v)
             loop.reset()
             loop.frame(); ctx.sync()                     # settle (scratch re-allocation, clocks)
-            ctx.profile_read(reset=True); ctx.profile_enable(True)
+            ctx.profile_read(reset=True); ctx.profile_enable(not args.no_profile)
             t0 = time.perf_counter()
             for _ in range(args.frames):
                 loop.frame()

@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""Turns the FETCH_SIZE / WRITE_SIZE passes of scripts/pmc_passes.sh (run on bench.py) into profiles/traffic.json, the
+file bench.py reads for roofline.traffic.
+  usage: traffic_from_pmc.py <pmc dir> <bench json of the same command> <out json>
+FETCH_SIZE is reported in KiB and, on gfx950, tallies a 128-byte memory-side read request as 64 bytes: it is doubled.
+That correction is calibrated for wide streaming reads; the traversal kernel reads 64-byte records at scattered
+addresses, for which the doubled figure is an upper bound.  WRITE_SIZE (KiB) is taken as is."""
+import csv
+import glob
+import json
+import os
+import sys
+
+NAMES = {"ptr_wf_extend<false": "wavefront.extend", "ptr_wf_shade<false": "wavefront.shade", "ptr_wf_generate": "wavefront.generate",
+         "ptr_wf_accumulate": "wavefront.accumulate", "ptr_compute_megakernel<false": "compute.megakernel"}
+
+
+def mean_per_kernel(directory, counter):
+    acc = {}
+    for f in glob.glob(os.path.join(directory, "**", "*counter_collection.csv"), recursive=True):
+        with open(f) as fh:
+            for r in csv.DictReader(fh):
+                if r["Counter_Name"] != counter:
+                    continue
+                for prefix, name in NAMES.items():
+                    if prefix in r["Kernel_Name"]:
+                        acc.setdefault(name, []).append(float(r["Counter_Value"]))
+    return {k: sum(v) / len(v) for k, v in acc.items()}, {k: len(v) for k, v in acc.items()}
+
+
+def main():
+    pmc_dir, bench_json, out = sys.argv[1:4]
+    fetch, n = mean_per_kernel(os.path.join(pmc_dir, "fetch"), "FETCH_SIZE")
+    write, _ = mean_per_kernel(os.path.join(pmc_dir, "write"), "WRITE_SIZE")
+    with open(bench_json) as f:
+        bench = json.loads(f.read().strip().splitlines()[-1])
+    kernels = {}
+    for name in fetch:
+        fb, wb = fetch[name] * 1024.0, write.get(name, 0.0) * 1024.0
+        kernels[name] = dict(fetch_size_kib=fetch[name], write_size_kib=write.get(name, 0.0), launches_sampled=n[name],
+                             bytes_per_launch=2.0 * fb + wb)
+    doc = dict(workload=bench["config"]["workload"], kernels=kernels,
+               note="per launch, mean over the launches of a short bench.py run under rocprofv3 --pmc (FETCH_SIZE and WRITE_SIZE in separate "
+                    "passes); bytes = 2 x FETCH_SIZE (gfx950 tallies 128-byte requests as 64) + WRITE_SIZE; the doubling is an upper bound for "
+                    "this kernel's scattered 64-byte reads; Infinity-Cache hits are included in FETCH_SIZE")
+    with open(out, "w") as f:
+        json.dump(doc, f, indent=1)
+    print(json.dumps(doc, indent=1))
+
+
+if __name__ == "__main__":
+    main()

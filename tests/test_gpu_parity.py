@@ -91,6 +91,47 @@ def test_pregathered_shading_records_change_nothing_and_follow_buffer_writes(ctx
     assert_same(img2, ref2, "after rewriting normals and uvs")
 
 
+def test_frames_in_flight_change_nothing(ctx):
+    """Consecutive frames are traced on internal streams, several in flight: the images are those of one stream, also when
+    the materials buffer is rewritten between two dispatches without any synchronisation by the caller."""
+    b = make_bundle("atrium", 4000, 88, 56, max_bounce=4)
+    gs = None
+    images = {}
+    for k in (1, 2, 3, 4):
+        ctx.set_option("frames.in_flight", k)
+        try:
+            img, gs, _, _ = gpu_frames(ctx, b, 7, "compute.wavefront", gpu_scene=gs)
+        finally:
+            ctx.set_option("frames.in_flight", 2)
+        images[k] = img
+    ref, _, _ = oracle_for(b, gs, 7, use_flat=True)
+    for k, img in images.items():
+        assert_same(img, ref, f"{k} frame(s) in flight vs oracle")
+
+    # frame 1..3 with the original materials, then every base colour halved, then frames 4..6: no sync in between
+    from path_tracer_amd import hip
+    dimmed = gs.materials_host.copy()
+    dimmed["base_color"][:, :3] *= np.float32(0.5)
+    results = {}
+    for k in (1, 3):
+        ctx.set_option("frames.in_flight", k)
+        try:
+            gs.materials_buffer.write(gs.materials_host)
+            gs.set_meta(b["meta"])
+            loop = hip.FrameLoop(ctx, gs, b["width"], b["height"], "compute.wavefront")
+            for _ in range(3):
+                loop.frame()
+            gs.materials_buffer.write(dimmed)
+            for _ in range(3):
+                loop.frame()
+            results[k] = loop.latest().read()
+        finally:
+            ctx.set_option("frames.in_flight", 2)
+            gs.materials_buffer.write(gs.materials_host)
+    assert_same(results[3], results[1], "materials rewritten between frames in flight")
+    assert not np.array_equal(results[1], images[1])
+
+
 def test_auto_pipeline_picks_wavefront_when_a_flat_layout_is_bound(ctx):
     b = make_bundle("tiny", 0, 48, 32, max_bounce=3)
     img_auto, gs, _, _ = gpu_frames(ctx, b, 2, "compute")
