@@ -404,8 +404,9 @@ static void launch_extend_variant(hipStream_t s, const FlatView& fv, const Wavef
 
 hipError_t launch_wf_extend(hipStream_t s, const FlatView& fv, const WavefrontScratch& w, uint32_t bounce, unsigned long long* stats,
                             int refill, int leaf_weight, int leaf_all, int inner_reps) {
-    if (stats) {
-        launch_extend_variant<true, 2, true, 1>(s, fv, w, bounce, stats, refill);
+    if (stats) {  // the counting variant follows inner_reps so that its step counts describe the timed configuration
+        if (inner_reps >= 3) launch_extend_variant<true, 2, true, 3>(s, fv, w, bounce, stats, refill);
+        else launch_extend_variant<true, 2, true, 1>(s, fv, w, bounce, stats, refill);
     } else if (!leaf_all) {
         launch_extend_variant<false, 2, false, 1>(s, fv, w, bounce, stats, refill);
     } else if (inner_reps == 1) {

@@ -7,11 +7,14 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--triangles", type=int, default=2_800_000); ap.add_argument("--scene", default="street_exterior")
 ap.add_argument("--width", type=int, default=1920); ap.add_argument("--height", type=int, default=1080)
 ap.add_argument("--texture-size", type=int, default=512); ap.add_argument("--bounces", type=int, default=4)
+ap.add_argument("--set", nargs="*", default=[], help="library options, key=value")
 args = ap.parse_args()
 import bench
 from path_tracer_amd import hip
 sc, nodes, flat, meta, _ = bench.build_scene(args, 0)
 ctx = hip.Context(0)
+for kv in args.set:
+    ctx.set_option(kv.split("=")[0], int(kv.split("=")[1]))
 gpu = hip.GpuScene(ctx, sc, nodes, flat, meta)
 loop = hip.FrameLoop(ctx, gpu, args.width, args.height, "compute")
 prev = None

@@ -1,0 +1,78 @@
+"""The measurement configurations of the hot-path contract at their real sizes, as far as one GPU and a CPU oracle
+that traces ~0.5 Mrays/s allow:
+  C2  atrium (Sponza-class) 1920x1080, max_bounce 2: primitive id and t of the first two hits against the oracle's own
+      traversal order on every pixel (ties counted, not hidden), and the image bit for bit;
+  C3  street interior 1920x1080, max_bounce 4, several samples: the oracle on sampled row bands, bit for bit
+      (stronger than the RMSE bound the contract asks for);
+  C4  street exterior 3840x2160 in tile mode over 4 ranks: the union of the ranks' stripes is bit-identical to the
+      single-GPU frame (the ranks are four partitions of one context here; the all-gather is tested on CPU)."""
+import numpy as np
+import pytest
+
+from common import gpu_frames, make_bundle, oracle_frames
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from path_tracer_amd import hip
+    c = hip.Context(0)
+    yield c
+    c.close()
+
+
+def test_c2_atrium_1080p_first_two_hits_and_image(ctx):
+    b = make_bundle("atrium", 262144, 1920, 1080, max_bounce=2)
+    assert 250_000 < b["triangles"].shape[0] < 275_000
+    img, gs, cap, st = gpu_frames(ctx, b, 1, "compute.wavefront", capture=True, stats=True)
+    mega, _, capm, _ = gpu_frames(ctx, b, 1, "compute.megakernel", gpu_scene=gs, capture=True)
+    # the oracle walks the reference's threaded tree in the reference's order (what the megakernel does too)
+    ref, counters, aov = oracle_frames(b, 1, materials=gs.materials_host, textures=gs.texture_table, aov=True, threads=16)
+    assert np.array_equal(mega, ref) and np.array_equal(capm[0], aov[0]) and np.array_equal(capm[1], aov[1])
+    # the fast path walks another tree: equal ids except the declared tie classes, equal t wherever the ids agree
+    for bounce in (0, 1):
+        same = cap[0][..., bounce] == aov[0][..., bounce]
+        assert int((~same).sum()) <= 40, int((~same).sum())
+        assert np.array_equal(cap[1][..., bounce][same], aov[1][..., bounce][same])
+    assert counters["nan_hits"] == 0
+    differing = np.abs(img - ref).max(axis=2) > 0
+    assert int(differing.sum()) <= 80, int(differing.sum())      # only pixels whose path went through a tie
+
+
+def test_c3_street_interior_1080p_sampled_bands(ctx):
+    import pyoracle
+    spp = 3
+    b = make_bundle("street_interior", 1_000_000, 1920, 1080, max_bounce=4)
+    assert 950_000 < b["triangles"].shape[0] < 1_050_000
+    img, gs, _, _ = gpu_frames(ctx, b, spp, "compute.wavefront")
+    o = pyoracle.OracleScene(dict(b, materials=gs.materials_host, textures=gs.texture_table))
+    acc = np.zeros((1080, 1920, 4), np.float32)
+    out = np.zeros_like(acc)
+    bands = [(0, 4), (268, 272), (540, 544), (812, 816), (1076, 1080)]
+    for s in range(1, spp + 1):
+        o.set_meta(sample_index=s)
+        for r in bands:
+            o.render(acc, out, rows=r, use_flat=True, threads=16)
+        acc, out = out, acc
+    for y0, y1 in bands:
+        assert np.array_equal(img[y0:y1], acc[y0:y1]), f"rows {y0}:{y1}"
+    assert np.isfinite(img).all() and img[..., :3].min() >= 0.0 and img[..., :3].max() <= 1.0 and (img[..., 3] == 1.0).all()
+
+
+def test_c4_street_exterior_4k_tile_mode(ctx):
+    W, H, world, spp = 3840, 2160, 4, 2
+    b = make_bundle("street_exterior", 400_000, W, H, max_bounce=4)
+    whole, gs, _, _ = gpu_frames(ctx, b, spp, "compute.wavefront")
+    stripe_of_row = (np.arange(H) // 8) % world
+    merged = np.zeros_like(whole)
+    try:
+        for rank in range(world):
+            ctx.set_partition(rank, world, 8)
+            part, _, _, _ = gpu_frames(ctx, b, spp, "compute.wavefront", gpu_scene=gs)
+            mine = stripe_of_row == rank
+            assert (part[~mine] == 0).all()                      # a rank never writes foreign rows
+            merged[mine] = part[mine]
+    finally:
+        ctx.set_partition(0, 1, 8)
+    assert np.array_equal(merged, whole)
