@@ -117,6 +117,10 @@ int ptr_set_sample_partition(ptr_ctx* ctx, uint32_t rank, uint32_t world);
  *                              3 is slower than 2 because a fourth active hardware queue costs more than it hides.)
  *      "profile.extend_only"   1: ptr_profile_enable records events around the traversal kernel only (the events between
  *                              the other kernels cost a few per cent of the frame rate); 0 (default): around every kernel.
+ *      "scene.index_words"     3 (default): the index buffer holds the reference's packing, three words per triangle, 24-bit
+ *                              vertex id | one byte of the 24-bit material id (src/scene.cpp:140-142, ray.h:20-30);
+ *                              4: extension for scenes with more than 2^24 vertices (no counterpart in the reference):
+ *                              four plain words per triangle, v0, v1, v2, material id; the buffer must be 16-byte aligned.
  *      "shade.pregather"       1 (default): the wavefront shade step reads one 80-byte record per hit triangle (vertex
  *                              normals, uvs, material id, geometry normal) that the library gathers once from the index /
  *                              positions / normals / uvs buffers of the dispatch and re-gathers after any ptr_buffer_write

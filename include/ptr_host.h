@@ -40,14 +40,16 @@ void ptrh_camera(const float pos[3], const float target[3], float v_fov, float a
 
 /* ---- glTF -> flat scene arrays: gltf::gltf(path) + the flattening loop of scene::scene -- reference:
  * src/gltf.cpp:14-195, src/mesh.cpp:5-37, src/scene.cpp:84-176.  *scene_out is an opaque flat scene; free it with
- * ptrh_scene_free.  apply_transforms 0 = node transforms ignored (what the reference does), 1 = applied. */
-int32_t ptrh_gltf_load(const char* path, int32_t apply_transforms, void** scene_out);
+ * ptrh_scene_free.  apply_transforms 0 = node transforms ignored (what the reference does), 1 = applied.
+ * wide_indices -1 = the reference's packed index words unless the scene has more than 2^24 vertices or material records,
+ * 0 = packed (fails for such a scene), 1 = always the 4-word extension (v0, v1, v2, material per triangle). */
+int32_t ptrh_gltf_load(const char* path, int32_t apply_transforms, int32_t wide_indices, void** scene_out);
 /* The same flat scene from a .ptrscene file (the headless driver's native container). */
 int32_t ptrh_scene_load(const char* path, void** scene_out);
-/* counts = { index words (3 per triangle), vertices, material records, textures } */
-int32_t ptrh_scene_counts(const void* scene, uint64_t counts[4]);
-/* Copies the arrays out (any pointer may be NULL): indices u32[counts[0]] (24-bit vertex id | one byte of the
- * material id, src/scene.cpp:140-142), positions/normals f32[3 * vertices], uvs f32[2 * vertices], materials
+/* counts = { index words in total, vertices, material records, textures, index words per triangle (3 or 4) } */
+int32_t ptrh_scene_counts(const void* scene, uint64_t counts[5]);
+/* Copies the arrays out (any pointer may be NULL): indices u32[counts[0]] (3 words per triangle: 24-bit vertex id | one byte
+ * of the material id, src/scene.cpp:140-142; or 4 plain words per triangle, see counts[4]), positions/normals f32[3 * vertices], uvs f32[2 * vertices], materials
  * counts[2] records of 32 bytes { f32 base_color[4]; u32 albedo_texture, mr_texture (1-based, 0 = none);
  * f32 metalness, roughness }. */
 int32_t ptrh_scene_arrays(const void* scene, uint32_t* indices, float* positions, float* normals, float* uvs, void* materials);

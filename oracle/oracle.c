@@ -266,7 +266,12 @@ typedef struct { v3 origin, direction; float min_t, max_t; } ray_t;
 typedef struct { v3 point, barycentrics, geometry_normal; float t; uint32_t primitive_id; } hit_t;
 
 static inline void decode_triangle_indices(const orc_frame* f, uint32_t tri, uint32_t out[4]) { /* ray.h:20-30 */
-    uint32_t a = f->indices[tri * 3], b = f->indices[tri * 3 + 1], c = f->indices[tri * 3 + 2];
+    if (f->index_words == 4) { /* wide extension: plain vertex ids and material id */
+        const uint32_t* w = f->indices + (size_t)tri * 4;
+        out[0] = w[0]; out[1] = w[1]; out[2] = w[2]; out[3] = w[3];
+        return;
+    }
+    uint32_t a = f->indices[(size_t)tri * 3], b = f->indices[(size_t)tri * 3 + 1], c = f->indices[(size_t)tri * 3 + 2];
     out[0] = a & 0x00ffffffu;
     out[1] = b & 0x00ffffffu;
     out[2] = c & 0x00ffffffu;

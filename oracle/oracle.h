@@ -71,6 +71,9 @@ typedef struct {
     float* aov_t;                /* 2 per pixel */
     const void* flat_bvh;        /* optional flattened-layout blob (header|nodes|triangles) */
     int32_t use_flat;            /* !=0: closest hits come from the flattened layout's traversal */
+    uint32_t index_words;        /* 0 or 3: the reference's packing (3 words per triangle, 24-bit vertex id | one byte of
+                                    the material id, src/scene.cpp:140-142); 4: extension for scenes past 2^24 vertices,
+                                    4 plain words per triangle: v0, v1, v2, material */
 } orc_frame;
 
 /* compute.comp main() over the rows [y0, y1) of the dispatch, `threads` worker threads. */

@@ -91,6 +91,7 @@ struct ptr_ctx {
     int opt_extend_leaf_weight = 2; // leaf lanes count this many times when a traversal wave picks its next step kind
     int opt_extend_refill = 16;     // idle lanes that trigger a refill of the traversal wave (8, 16, 32, 48, 64)
     int opt_extend_blocks_per_cu = 7;
+    int opt_index_words = 3;        // layout of the index buffer: 3 = the reference's packed words, 4 = v0, v1, v2, material
     int opt_shade_pregather = 1;    // wavefront shade reads per-triangle records gathered once per scene
     // the records, and what they were built from: addresses + write generations of indices / positions / normals / uvs
     void* shade_records = nullptr;
@@ -303,14 +304,16 @@ int ensure_shade_records(ptr_ctx* c, const uint64_t addr[7], const ptr_handle ha
         const BufferRec& b = c->buffers[handles[i]];
         return (uint64_t)(uintptr_t)b.ptr + b.size - addr[i];
     };
-    const uint64_t tris = bytes_from(2) / 12u;
+    const uint64_t tris = bytes_from(2) / (4u * (uint64_t)c->opt_index_words);
     uint64_t vertices = bytes_from(3) / 12u;
     if (bytes_from(4) / 12u < vertices) vertices = bytes_from(4) / 12u;
     if (bytes_from(5) / 8u < vertices) vertices = bytes_from(5) / 8u;
     if (tris == 0 || vertices == 0 || tris > 0x7fffffffull) return PTR_OK;
-    if (vertices > (1u << 24)) vertices = 1u << 24;  // the packed index words hold 24-bit vertex ids
+    if (c->opt_index_words == 3 && vertices > (1u << 24)) vertices = 1u << 24;  // the packed index words hold 24-bit vertex ids
+    if (vertices > 0xffffffffull) vertices = 0xffffffffull;
     uint64_t key[8];
     for (int i = 0; i < 4; i++) { key[i] = addr[2 + i]; key[4 + i] = c->buffers[handles[2 + i]].generation; }
+    key[0] ^= (uint64_t)c->opt_index_words << 60;  // device addresses leave the top bits free
     if (c->shade_key_valid && c->shade_record_count == tris && !memcmp(key, c->shade_key, sizeof key)) {
         sv->shade_records = (const float4*)c->shade_records;
         sv->shade_record_count = c->shade_record_count;
@@ -362,6 +365,8 @@ int dispatch_compute(ptr_ctx* c, const uint8_t constants[64], uint32_t gx, uint3
     sv.meta = meta;
     sv.nodes = (const ptr::ThreadedNode*)(uintptr_t)k.addr[1];
     sv.indices = (const uint32_t*)(uintptr_t)k.addr[2];
+    sv.index_words = (uint32_t)c->opt_index_words;
+    if (c->opt_index_words == 4 && (k.addr[2] & 15u)) return fail(c, PTR_E_STATE, "constant block: a 4-word index buffer must be 16-byte aligned");
     sv.positions = (const float*)(uintptr_t)k.addr[3];
     sv.normals = (const float*)(uintptr_t)k.addr[4];
     sv.uvs = (const float*)(uintptr_t)k.addr[5];
@@ -862,6 +867,11 @@ int ptr_set_option(ptr_ctx* c, const char* key, int value) {
         int rc = bind_device(c); if (rc) return rc;
         if ((rc = drain_frames(c))) return rc;
         c->opt_frames_in_flight = value;
+        return PTR_OK;
+    }
+    if (!strcmp(key, "scene.index_words")) {
+        if (value != 3 && value != 4) return fail(c, PTR_E_INVALID, "scene.index_words: 3 or 4");
+        c->opt_index_words = value;
         return PTR_OK;
     }
     if (!strcmp(key, "shade.pregather")) {

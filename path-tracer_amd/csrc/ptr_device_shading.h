@@ -54,6 +54,7 @@ struct SceneView {
     unsigned long long* stats; // optional: [rays, nodes, triangles, shaded]
     uint32_t part_rank, part_world, part_stripe_rows;  // tile partition: stripes of rows
     uint32_t sample_rank, sample_world;                 // sample partition: which global samples this GPU draws
+    uint32_t index_words;      // 3: the reference's packed index words; 4: v0, v1, v2, material as plain words
     const float4* shade_records;  // optional: kShadeRecordVec4 float4 per triangle, see ShadeInputs / gather_shade_inputs
     uint32_t shade_record_count;
 };
@@ -218,6 +219,11 @@ PTR_DEV f4 sample_bindless(const SceneView& sv, uint32_t texture_id, float u, fl
 
 // ---- ray.h:20-54 ----------------------------------------------------------------------------------------
 PTR_DEV void decode_triangle(const SceneView& sv, uint32_t tri, uint32_t& i0, uint32_t& i1, uint32_t& i2, uint32_t& mat) {
+    if (sv.index_words == 4u) {  // extension for scenes past 2^24 vertices: four plain words per triangle
+        const uint4 w = ((const uint4*)sv.indices)[tri];
+        i0 = w.x; i1 = w.y; i2 = w.z; mat = w.w;
+        return;
+    }
     const uint32_t a = sv.indices[tri * 3u], b = sv.indices[tri * 3u + 1u], c = sv.indices[tri * 3u + 2u];
     i0 = a & 0x00ffffffu; i1 = b & 0x00ffffffu; i2 = c & 0x00ffffffu;
     mat = ((a & 0xff000000u) >> 8) | ((b & 0xff000000u) >> 16) | ((c & 0xff000000u) >> 24);

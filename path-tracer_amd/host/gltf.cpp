@@ -382,8 +382,24 @@ void gltf::load_materials() {
     }
 }
 
-scene_source gltf::flatten(bool apply_transforms) const {
+scene_source gltf::flatten(bool apply_transforms, int wide_indices) const {
     scene_source out;
+    // what the flat scene will hold, to pick the index layout before the first word is written
+    {
+        size_t total_vertices = 0, total_materials = 0;
+        std::queue<const node*> walk;
+        walk.push(&root_node);
+        while (!walk.empty()) {
+            const node* n = walk.front();
+            walk.pop();
+            if (n->mesh) { total_vertices += n->mesh->vertices_count(); total_materials += n->mesh->get_submeshes().size(); }
+            for (const node& child : n->children) walk.push(&child);
+        }
+        const bool fits = total_vertices < (1u << 24) && total_materials < (1u << 24);
+        if (wide_indices == 0 && !fits) throw gltf_error("gltf: more than 2^24 vertices or material records do not fit the packed index words");
+        if (total_vertices > 0xffffffffull) throw gltf_error("gltf: more than 2^32 vertices");
+        out.index_words = (wide_indices == 1 || (wide_indices < 0 && !fits)) ? 4u : 3u;
+    }
     // textures: one per glTF texture, numbered as the materials number them
     for (uint32_t image_index : textures) {
         const raw_image& im = images[image_index];
@@ -410,7 +426,6 @@ scene_source gltf::flatten(bool apply_transforms) const {
             const auto& mesh_normals = mesh->get_attribute(ATTRIBUTE_TYPE::NORMAL);
             const auto& mesh_uvs_0 = mesh->get_attribute(ATTRIBUTE_TYPE::UV_0);
             const auto& mesh_indices = mesh->get_indices();
-            if (vertices_offset + mesh->vertices_count() >= (1u << 24)) throw gltf_error("gltf: more than 2^24 vertices do not fit the packed index words");
 
             if (!apply_transforms) {
                 out.positions.insert(out.positions.end(), mesh_positions.begin(), mesh_positions.end());
@@ -437,9 +452,13 @@ scene_source gltf::flatten(bool apply_transforms) const {
             for (const auto& submesh : mesh->get_submeshes()) {
                 const size_t vertex_offset = vertices_offset + submesh.vertex_offset;
                 const size_t material_id = out.materials.size();
-                if (material_id >= (1u << 24)) throw gltf_error("gltf: more than 2^24 material records");
                 for (size_t e = 0; e < submesh.element_count; e++) {
                     const size_t at = submesh.index_offset + e * 3;
+                    if (out.index_words == 4) {
+                        for (int k = 0; k < 3; k++) out.indices.push_back((uint32_t)(mesh_indices[at + k] + vertex_offset));
+                        out.indices.push_back((uint32_t)material_id);
+                        continue;
+                    }
                     // vertex id in the low 24 bits, one byte of the material id on top of each word (src/scene.cpp:140-142)
                     out.indices.push_back((uint32_t)((mesh_indices[at] + vertex_offset) | (0xff000000u & (material_id << 8))));
                     out.indices.push_back((uint32_t)((mesh_indices[at + 1] + vertex_offset) | (0xff000000u & (material_id << 16))));

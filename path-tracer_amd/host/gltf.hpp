@@ -41,7 +41,9 @@ public:
 
     // What src/scene.cpp:84-176 does with the node tree: breadth-first over the nodes, every mesh appended to the
     // flat arrays, one material record per submesh visited, indices made absolute and packed with the material id.
-    scene_source flatten(bool apply_transforms = false) const;
+    // wide_indices: -1 = the 4-word index layout only when the packed one cannot hold the scene, 0 = packed (throws
+    // when it cannot), 1 = always 4 words.
+    scene_source flatten(bool apply_transforms = false, int wide_indices = -1) const;
 
     const std::vector<Mesh>& get_meshes() const { return meshes; }
     const std::vector<scene_source::source_material>& get_materials() const { return materials; }

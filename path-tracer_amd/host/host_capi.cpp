@@ -104,11 +104,11 @@ void ptrh_camera(const float pos[3], const float target[3], float v_fov, float a
 }
 
 // ---- glTF -> flat scene arrays ---------------------------------------------------------------------------
-int32_t ptrh_gltf_load(const char* path, int32_t apply_transforms, void** scene_out) {
+int32_t ptrh_gltf_load(const char* path, int32_t apply_transforms, int32_t wide_indices, void** scene_out) {
     try {
         if (!path || !scene_out) { g_last_error = "ptrh_gltf_load: null argument"; return -1; }
         const gltf model{ std::string(path) };
-        *scene_out = new scene_source(model.flatten(apply_transforms != 0));
+        *scene_out = new scene_source(model.flatten(apply_transforms != 0, wide_indices));
         return 0;
     } catch (const std::exception& e) {
         g_last_error = e.what();
@@ -127,10 +127,11 @@ int32_t ptrh_scene_load(const char* path, void** scene_out) {
     }
 }
 
-int32_t ptrh_scene_counts(const void* scene, uint64_t counts[4]) {
+int32_t ptrh_scene_counts(const void* scene, uint64_t counts[5]) {
     if (!scene || !counts) { g_last_error = "ptrh_scene_counts: null argument"; return -1; }
     const scene_source* s = (const scene_source*)scene;
     counts[0] = s->indices.size(); counts[1] = s->positions.size() / 3; counts[2] = s->materials.size(); counts[3] = s->textures.size();
+    counts[4] = s->index_words;
     return 0;
 }
 

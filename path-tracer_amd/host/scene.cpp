@@ -10,10 +10,13 @@
 scene::metadata::metadata(const camera& cam_, uint32_t width_, uint32_t height_) : cam(cam_), width(width_), height(height_) {}
 
 scene::scene(const camera& cam, uint32_t width, uint32_t height, const scene_source& src, bool flatten_bvh) : meta(cam, width, height) {
-    if (src.indices.empty() || src.indices.size() % 3) throw std::runtime_error("scene: index count must be a positive multiple of 3");
+    const uint32_t iw = src.index_words;
+    if (iw != 3 && iw != 4) throw std::runtime_error("scene: index_words must be 3 or 4");
+    if (src.indices.empty() || src.indices.size() % iw) throw std::runtime_error("scene: the index array must hold whole triangles");
     const size_t vertex_count = src.positions.size() / 3;
-    if (vertex_count >= (1u << 24)) throw std::runtime_error("scene: more than 2^24 vertices do not fit the packed index words");
-    if (src.materials.size() >= (1u << 24)) throw std::runtime_error("scene: more than 2^24 materials");
+    if (iw == 3 && vertex_count >= (1u << 24)) throw std::runtime_error("scene: more than 2^24 vertices do not fit the packed index words");
+    if (iw == 3 && src.materials.size() >= (1u << 24)) throw std::runtime_error("scene: more than 2^24 materials");
+    hiprenderer::check(ptr_set_option(hiprenderer::api, "scene.index_words", (int)iw), "ptr_set_option(scene.index_words)");
 
     // textures + the one LINEAR / REPEAT sampler the reference creates (src/gltf.cpp:118)
     sampler = hiprenderer::create_sampler(PTR_FILTER_LINEAR, PTR_ADDRESS_REPEAT);
@@ -46,11 +49,11 @@ scene::scene(const camera& cam, uint32_t width, uint32_t height, const scene_sou
 
     // triangles for the builder: corners fetched through the 24-bit vertex indices (src/scene.cpp:132-136)
     std::vector<triangle> triangles;
-    triangles.reserve(src.indices.size() / 3);
-    for (size_t i = 0; i < src.indices.size(); i += 3) {
+    triangles.reserve(src.indices.size() / iw);
+    for (size_t i = 0; i < src.indices.size(); i += iw) {
         vec3 p[3];
         for (int k = 0; k < 3; k++) {
-            const uint32_t v = src.indices[i + k] & 0x00ffffffu;
+            const uint32_t v = iw == 3 ? (src.indices[i + k] & 0x00ffffffu) : src.indices[i + k];
             if (v >= vertex_count) throw std::runtime_error("scene: vertex index out of range");
             p[k] = vec3(src.positions[v * 3], src.positions[v * 3 + 1], src.positions[v * 3 + 2]);
         }

@@ -4,7 +4,7 @@
 #include <cstring>
 #include <stdexcept>
 
-// .ptrscene: little-endian, "PTRS", u32 version = 1, u32 index_words, u32 vertices, u32 materials, u32 textures,
+// .ptrscene: little-endian, "PTRS", u32 version = 1 (3 index words per triangle) or 2 (4 words: v0, v1, v2, material), u32 index_words, u32 vertices, u32 materials, u32 textures,
 // then indices, positions, normals, uvs, materials (48 bytes: base_color[4], albedo texture, unused, mr texture,
 // unused, metalness, roughness, pad[2]), then per texture u32 width, u32 height, RGBA8 texels.
 scene_source scene_source::load(const std::string& path) {
@@ -13,8 +13,9 @@ scene_source scene_source::load(const std::string& path) {
     auto read = [&](void* dst, size_t n) { if (n && std::fread(dst, 1, n, f) != n) { std::fclose(f); throw std::runtime_error("scene_source::load: truncated " + path); } };
     uint32_t head[6];
     read(head, sizeof head);
-    if (std::memcmp(&head[0], "PTRS", 4) != 0 || head[1] != 1) { std::fclose(f); throw std::runtime_error("scene_source::load: not a .ptrscene v1 file"); }
+    if (std::memcmp(&head[0], "PTRS", 4) != 0 || (head[1] != 1 && head[1] != 2)) { std::fclose(f); throw std::runtime_error("scene_source::load: not a .ptrscene v1/v2 file"); }
     scene_source s;
+    s.index_words = head[1] == 2 ? 4u : 3u;
     s.indices.resize(head[2]);
     s.positions.resize((size_t)head[3] * 3);
     s.normals.resize((size_t)head[3] * 3);

@@ -8,7 +8,11 @@
 #include <vector>
 
 struct scene_source {
-    std::vector<uint32_t> indices;     // 3 per triangle: 24-bit vertex index | one byte of the 24-bit material id
+    // 3 words per triangle: 24-bit vertex index | one byte of the 24-bit material id (src/scene.cpp:140-142), or,
+    // for scenes past 2^24 vertices or materials (an extension), 4 plain words per triangle: v0, v1, v2, material
+    uint32_t index_words = 3;
+    std::vector<uint32_t> indices;
+    size_t triangle_count() const { return indices.size() / index_words; }
     std::vector<float> positions;      // 3 per vertex
     std::vector<float> normals;        // 3 per vertex
     std::vector<float> uvs;            // 2 per vertex

@@ -334,6 +334,7 @@ class GpuScene:
             return b
         self.scene_buffer = ctx.create_buffer(160 * 2)
         self.bvh_buffer = upload(nodes)
+        self.index_words = int(arrays.get("index_words", 3))
         self.indices_buffer = upload(np.asarray(arrays["indices"], dtype=np.uint32))
         self.positions_buffer = upload(np.asarray(arrays["positions"], dtype=np.float32))
         self.normals_buffer = upload(np.asarray(arrays["normals"], dtype=np.float32))
@@ -361,6 +362,7 @@ class GpuScene:
 
     def wire(self, renderpass):
         """src/main.cpp:263-269"""
+        self.ctx.set_option("scene.index_words", self.index_words)   # a context-wide setting: the layout of this scene's index buffer
         renderpass.set_constant(0, self.scene_buffer)
         renderpass.set_constant(8, self.bvh_buffer)
         renderpass.set_constant(16, self.indices_buffer)

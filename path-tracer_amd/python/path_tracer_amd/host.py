@@ -23,7 +23,7 @@ def lib():
         L.ptrh_camera.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p,
                                   C.c_int32, C.c_void_p]
         vp = C.c_void_p
-        L.ptrh_gltf_load.argtypes = [C.c_char_p, C.c_int32, C.POINTER(vp)]
+        L.ptrh_gltf_load.argtypes = [C.c_char_p, C.c_int32, C.c_int32, C.POINTER(vp)]
         L.ptrh_scene_load.argtypes = [C.c_char_p, C.POINTER(vp)]
         L.ptrh_scene_counts.argtypes = [vp, C.POINTER(C.c_uint64)]
         L.ptrh_scene_arrays.argtypes = [vp, vp, vp, vp, vp, vp]
@@ -113,10 +113,10 @@ SOURCE_MATERIAL_DTYPE = np.dtype([("base_color", np.float32, 4), ("albedo_tex", 
 def _scene_to_dict(handle):
     L = lib()
     try:
-        counts = (C.c_uint64 * 4)()
+        counts = (C.c_uint64 * 5)()
         if L.ptrh_scene_counts(handle, counts) != 0:
             raise HostError(L.ptrh_last_error().decode())
-        n_idx, n_vtx, n_mat, n_tex = (int(c) for c in counts)
+        n_idx, n_vtx, n_mat, n_tex, index_words = (int(c) for c in counts)
         out = dict(indices=np.zeros(n_idx, np.uint32), positions=np.zeros(n_vtx * 3, np.float32), normals=np.zeros(n_vtx * 3, np.float32),
                    uvs=np.zeros(n_vtx * 2, np.float32))
         mats = np.zeros(n_mat, SOURCE_MATERIAL_DTYPE)
@@ -140,7 +140,8 @@ def _scene_to_dict(handle):
                 raise HostError(L.ptrh_last_error().decode())
             textures.append(t)
         out["textures"] = textures
-        vid = out["indices"] & np.uint32(0x00FFFFFF)
+        out["index_words"] = index_words
+        vid = (out["indices"] & np.uint32(0x00FFFFFF)) if index_words == 3 else out["indices"].reshape(-1, 4)[:, :3].reshape(-1)
         out["triangles"] = np.ascontiguousarray(out["positions"].reshape(-1, 3)[vid].reshape(-1, 9))
         out["primitive_count"] = n_mat
         return out
@@ -148,10 +149,10 @@ def _scene_to_dict(handle):
         L.ptrh_scene_free(handle)
 
 
-def gltf_load(path, apply_transforms=False):
+def gltf_load(path, apply_transforms=False, wide_indices=-1):
     """gltf(path).flatten(): the flat scene arrays (same dict layout as scenes.generate, without a camera)."""
     h = C.c_void_p()
-    if lib().ptrh_gltf_load(os.fsencode(path), 1 if apply_transforms else 0, C.byref(h)) != 0:
+    if lib().ptrh_gltf_load(os.fsencode(path), 1 if apply_transforms else 0, wide_indices, C.byref(h)) != 0:
         raise HostError(lib().ptrh_last_error().decode())
     return _scene_to_dict(h)
 

@@ -341,6 +341,46 @@ def tiny_scene(seed=1):
                 primitive_count=b.prim_count)
 
 
+def widen_indices(scene):
+    """The same scene with the 4-word index layout (v0, v1, v2, material per triangle) instead of the reference's packed
+    3 words: the extension for scenes past 2^24 vertices."""
+    idx = np.asarray(scene["indices"], np.uint32).reshape(-1, 3)
+    mat = ((idx[:, 0] >> 24) << 16) | ((idx[:, 1] >> 24) << 8) | (idx[:, 2] >> 24)
+    wide = np.concatenate([idx & np.uint32(0x00FFFFFF), mat[:, None]], axis=1).astype(np.uint32)
+    return dict(scene, indices=wide.reshape(-1), index_words=4)
+
+
+def instance_grid(scene, nx, nz, spacing=None):
+    """nx * nz translated copies of `scene` on a grid in x and z, as ONE flat scene in the 4-word index layout (the
+    copies share the materials and textures).  This is how a 10^8-triangle scene is made from a 3 * 10^6-triangle one."""
+    base = widen_indices(scene) if int(scene.get("index_words", 3)) == 3 else scene
+    P = np.asarray(base["positions"], np.float32).reshape(-1, 3)
+    N = np.asarray(base["normals"], np.float32).reshape(-1, 3)
+    U = np.asarray(base["uvs"], np.float32).reshape(-1, 2)
+    I = np.asarray(base["indices"], np.uint32).reshape(-1, 4)
+    extent = P.max(axis=0) - P.min(axis=0)
+    if spacing is None:
+        spacing = (float(extent[0]) * 1.02, float(extent[2]) * 1.02)
+    copies = nx * nz
+    nv = P.shape[0]
+    assert copies * nv < 2 ** 32
+    positions = np.empty((copies, nv, 3), np.float32)
+    indices = np.empty((copies, I.shape[0], 4), np.uint32)
+    k = 0
+    for ix in range(nx):
+        for iz in range(nz):
+            offset = np.array([(ix - (nx - 1) / 2.0) * spacing[0], 0.0, (iz - (nz - 1) / 2.0) * spacing[1]], np.float32)
+            positions[k] = P + offset
+            indices[k, :, :3] = I[:, :3] + np.uint32(k * nv)
+            indices[k, :, 3] = I[:, 3]
+            k += 1
+    positions = positions.reshape(-1, 3)
+    out = dict(base, positions=positions.reshape(-1), normals=np.tile(N, (copies, 1)).reshape(-1), uvs=np.tile(U, (copies, 1)).reshape(-1),
+               indices=indices.reshape(-1), index_words=4, kind=f"{scene.get('kind', 'scene')} x{copies}")
+    out["triangles"] = np.ascontiguousarray(positions[indices.reshape(-1, 4)[:, :3].reshape(-1)].reshape(-1, 9))
+    return out
+
+
 def pack_metadata(camera_block, width, height, max_bounce=3, min_bounce=1, sample_index=1, enable_dof=0, debug_bvh=0,
                   downscale_factor=1):
     """160-byte scene metadata: the 128-byte camera followed by eight 32-bit words
@@ -359,7 +399,7 @@ def save_ptrscene(scene, path):
     with open(path, "wb") as f:
         n_vertices = len(scene["positions"]) // 3
         f.write(b"PTRS")
-        f.write(np.array([1, len(scene["indices"]), n_vertices, len(scene["materials"]), len(textures)], dtype="<u4").tobytes())
+        f.write(np.array([2 if int(scene.get("index_words", 3)) == 4 else 1, len(scene["indices"]), n_vertices, len(scene["materials"]), len(textures)], dtype="<u4").tobytes())
         f.write(np.ascontiguousarray(scene["indices"], dtype="<u4").tobytes())
         f.write(np.ascontiguousarray(scene["positions"], dtype="<f4").tobytes())
         f.write(np.ascontiguousarray(scene["normals"], dtype="<f4").tobytes())

@@ -226,6 +226,21 @@ def test_gltf_tiny_scene_with_untextured_material_and_u8_indices(tmp_path):
     assert (got["materials"]["albedo_tex"] == 0).any()     # no baseColorTexture -> texture 0 (opaque white in the kernels)
 
 
+def test_gltf_wide_index_layout(tmp_path):
+    """wide_indices=1: four plain words per triangle (the layout for scenes past 2^24 vertices) naming the same triangles."""
+    sc = scenes.generate("atrium", 3000, texture_size=8)
+    path = gltf_io.save_gltf(sc, str(tmp_path), "wide")
+    packed, wide = host.gltf_load(path), host.gltf_load(path, wide_indices=1)
+    assert packed["index_words"] == 3 and wide["index_words"] == 4
+    want = scenes.widen_indices(sc)
+    assert np.array_equal(wide["indices"], want["indices"])
+    assert np.array_equal(wide["triangles"], packed["triangles"])
+    p = str(tmp_path / "wide.ptrscene")
+    scenes.save_ptrscene(want, p)
+    back = host.ptrscene_load(p)
+    assert back["index_words"] == 4 and np.array_equal(back["indices"], want["indices"])
+
+
 def test_ptrscene_file_round_trip(tmp_path):
     sc = scenes.tiny_scene()
     p = str(tmp_path / "tiny.ptrscene")

@@ -64,6 +64,23 @@ def test_headless_driver_renders_a_gltf_file_like_the_oracle(tmp_path, container
     assert np.array_equal(img, ref), f"{int((np.abs(img - ref).max(axis=2) > 0).sum())} pixels differ\n{r.stderr}"
 
 
+def test_headless_driver_wide_index_scene(tmp_path):
+    W, H, SPP = 64, 40, 2
+    b = make_bundle("atrium", 3000, W, H, max_bounce=4)
+    wide = scenes.widen_indices(b)
+    scene_file = str(tmp_path / "wide.ptrscene")
+    out_file = str(tmp_path / "out.pfm")
+    scenes.save_ptrscene(wide, scene_file)
+    c = b["camera"]
+    cmd = [HEADLESS, "--scene", scene_file, "--width", str(W), "--height", str(H), "--spp", str(SPP), "--max-bounce", "4",
+           "--out", out_file, "--pos", *map(str, c["pos"]), "--target", *map(str, c["target"]),
+           "--fov", str(c["v_fov"]), "--aperture", str(c["aperture"]), "--focus", str(c["focus"])]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    ref, _, _ = oracle_frames(wide, SPP, use_flat=True)
+    assert np.array_equal(read_ptrf(out_file), ref)
+
+
 def test_headless_reports_errors():
     r = subprocess.run([HEADLESS, "--scene", "/nonexistent.ptrscene"], capture_output=True, text=True, timeout=60)
     assert r.returncode == 1 and "cannot open" in r.stderr
