@@ -33,6 +33,23 @@ def build_scene(args, rank):
     from path_tracer_amd import host, scenes
     t0 = time.time()
     sc = scenes.generate(args.scene, args.triangles, texture_size=args.texture_size)
+    instanced = getattr(args, "instances", "1x1") not in ("", "1x1")
+    if instanced:
+        # the 10^8-triangle class: translated copies of the scene on a grid, one flat scene in the 4-word index layout.
+        # The reference's single-threaded builder and its 2N-1 node array (minutes, 13 GB at 10^8 triangles) are skipped:
+        # the wavefront path never reads the threaded tree; a one-leaf placeholder stands in for the node buffer.
+        nx, nz = (int(v) for v in args.instances.lower().split("x"))
+        sc = scenes.instance_grid(sc, nx, nz)
+        t1 = time.time()
+        nodes = np.zeros((1, 8), np.uint32)
+        nodes[0, 3] = 0xFFFFFFFF
+        flat = host.bvh_flatten(sc["triangles"], None, threads=min(16, os.cpu_count() or 1))
+        t3 = time.time()
+        c = sc["camera"]
+        cam = host.camera(c["pos"], c["target"], c["v_fov"], args.width / args.height, c["aperture"], c["focus"])
+        meta = scenes.pack_metadata(cam, args.width, args.height, max_bounce=args.bounces, min_bounce=1)
+        log(rank, f"scene {sc['kind']}: {sc['triangles'].shape[0]} triangles; generate {t1 - t0:.1f}s, flattened BVH {t3 - t1:.1f}s")
+        return sc, nodes, flat, meta, dict(generate_s=t1 - t0, threaded_bvh_s=0.0, flatten_s=t3 - t1, threaded_mode="none (placeholder)")
     t1 = time.time()
     try:
         nodes = host.bvh_build(sc["triangles"], host.REFERENCE_ORDER)
@@ -63,6 +80,7 @@ def cpu_baseline(args, sc, nodes, flat, meta, gpu_scene, budget_s):
     arrays = dict(sc, meta=meta, nodes=nodes, flat=flat, materials=gpu_scene.materials_host, textures=gpu_scene.texture_table)
     o = pyoracle.OracleScene(arrays)
     o.set_meta(sample_index=1)
+    use_flat = nodes.shape[0] < 2 * sc["triangles"].shape[0] - 1     # no threaded tree was built: walk the flattened layout
     H, W = args.height, args.width
     acc = np.zeros((H, W, 4), np.float32)
     out = np.zeros_like(acc)
@@ -73,7 +91,7 @@ def cpu_baseline(args, sc, nodes, flat, meta, gpu_scene, budget_s):
     rows_done = 0
     t0 = time.time()
     for y in order:
-        c = o.render(acc, out, rows=(y, y + band), threads=threads)
+        c = o.render(acc, out, rows=(y, y + band), threads=threads, use_flat=use_flat)
         rays += c["rays"]
         rows_done += band
         if time.time() - t0 >= budget_s:
@@ -81,7 +99,7 @@ def cpu_baseline(args, sc, nodes, flat, meta, gpu_scene, budget_s):
     dt = time.time() - t0
     return dict(value=rays / dt / 1e6, unit="Mrays/s", cores=threads, kind="port",
                 sample=f"{rows_done} of {H} rows ({rows_done // band} bands of {band} rows spread over the frame), sample_index 1, "
-                       f"{rays} rays in {dt:.1f}s, reference-order threaded BVH")
+                       f"{rays} rays in {dt:.1f}s, " + ("flattened BVH" if use_flat else "reference-order threaded BVH"))
 
 
 def pmc_traffic(kernel, workload):
@@ -111,6 +129,7 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--bounces", type=int, default=4)
     ap.add_argument("--texture-size", type=int, default=512)
+    ap.add_argument("--instances", default="1x1", help="NXxNZ translated copies of the scene on a grid (e.g. 6x6 of the default scene = 10^8 triangles)")
     ap.add_argument("--pipeline", default="compute", choices=["compute", "compute.megakernel", "compute.wavefront"])
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline leg (0 = skip)")
     ap.add_argument("--stream", default="torch", choices=["torch", "own"], help="the context's stream: torch's current stream or its own")
@@ -245,7 +264,7 @@ def main():
             node_bytes, tri_bytes = (64, 64) if wavefront else (32, 48)
             algo_bytes = node_bytes * stats["nodes"] + tri_bytes * stats["triangles"]  # this rank's launches
             achieved = algo_bytes / (k["total_ms"] * 1e-3) / 1e9 if k["total_ms"] > 0 else 0.0
-            line_workload = (f"{args.scene} (Bistro-Exterior-class procedural stand-in), {sc['triangles'].shape[0]} triangles, "
+            line_workload = (f"{sc['kind']} (Bistro-Exterior-class procedural stand-in), {sc['triangles'].shape[0]} triangles, "
                              f"{W}x{H}, 1 spp per step, max_bounce {args.bounces}, min_bounce 1, dof off")
             ks = solo.get(dominant, dict(launches=0, total_ms=0.0))
             solo_bytes = algo_bytes * ks["launches"] / max(1, k["launches"])
