@@ -191,6 +191,7 @@ raw_image decode_jpeg(const uint8_t* bytes, size_t size) {
             height = be16(seg + 1); width = be16(seg + 3);
             const int nc = seg[5];
             if (width == 0 || height == 0) throw image_error("jpeg: bad dimensions");
+            if ((uint64_t)width * height > (1ull << 28)) throw image_error("jpeg: more than 2^28 pixels");
             if ((nc != 1 && nc != 3) || n < (size_t)(6 + 3 * nc)) throw image_error("jpeg: only 1 or 3 components are supported");
             comps.resize(nc);
             for (int c = 0; c < nc; c++) {

@@ -230,6 +230,7 @@ raw_image decode_png(const uint8_t* bytes, size_t size) {
             width = be32(data); height = be32(data + 4);
             depth = data[8]; colour = data[9]; interlace = data[12];
             if (width == 0 || height == 0 || width > (1u << 24) || height > (1u << 24)) throw image_error("png: bad dimensions");
+            if ((uint64_t)width * height > (1ull << 28)) throw image_error("png: more than 2^28 pixels");
             if (data[10] != 0 || data[11] != 0 || interlace > 1) throw image_error("png: unknown compression, filter or interlace method");
             const bool ok = (colour == 0 && (depth == 1 || depth == 2 || depth == 4 || depth == 8 || depth == 16)) ||
                             (colour == 3 && (depth == 1 || depth == 2 || depth == 4 || depth == 8)) ||
