@@ -103,6 +103,9 @@ PTR_DEV void sort_pair(float& ka, int32_t& ra, float& kb, int32_t& rb) {
 // address spaces apart instead of falling back to a flat load).
 PTR_DEV int32_t stack_pop(const int32_t* lds, const int32_t* spill, uint32_t sp) {
     int32_t v = lds[(sp < kStackLds ? sp : 0u) * 64u];
+    // keep the LDS read a ds_read: without this fence the compiler folds both reads into one flat load of a selected
+    // address, which goes through the vector-memory pipeline on every pop
+    asm volatile("" : "+v"(v));
     if (sp >= kStackLds) v = spill[(sp - kStackLds) * 64u];
     return v;
 }

@@ -160,6 +160,34 @@ def test_wide_index_layout_and_instanced_grid(ctx):
     ctx.set_option("scene.index_words", 3)
 
 
+def test_frames_in_flight_survive_stream_changes_and_teardown():
+    """Frames in flight when the caller changes the context's stream, reads back, or destroys the context."""
+    import ctypes
+    from path_tracer_amd import hip
+    b = make_bundle("atrium", 3000, 64, 40, max_bounce=4)
+    c = hip.Context(0)
+    runtime = ctypes.CDLL("libamdhip64.so")          # the HIP runtime the library itself is linked against
+    side = ctypes.c_void_p()
+    assert runtime.hipStreamCreate(ctypes.byref(side)) == 0
+    try:
+        gs = hip.GpuScene(c, b, b["nodes"], b["flat"], b["meta"])
+        loop = hip.FrameLoop(c, gs, b["width"], b["height"], "compute.wavefront")
+        for i in range(6):
+            if i == 2:
+                c.set_stream(side.value)             # frames 0, 1 are in flight on the old stream
+            if i == 4:
+                c.set_stream(None)
+            loop.frame()
+        img = loop.latest().read()
+        ref, _, _ = oracle_for(b, gs, 6, use_flat=True)
+        assert_same(img, ref, "six frames across two stream changes")
+        for _ in range(5):
+            loop.frame()                             # destroyed with frames in flight
+    finally:
+        c.close()
+        runtime.hipStreamDestroy(side)
+
+
 def test_auto_pipeline_picks_wavefront_when_a_flat_layout_is_bound(ctx):
     b = make_bundle("tiny", 0, 48, 32, max_bounce=3)
     img_auto, gs, _, _ = gpu_frames(ctx, b, 2, "compute")
