@@ -135,7 +135,7 @@ int ptr_set_capture(ptr_ctx* ctx, ptr_handle buffer);
 /* Traversal counters: when on, "compute" dispatches run counting kernel variants.
  * out[0..4] = rays, node records fetched, triangle records fetched, shaded hits, frames;
  * out[5..6] = wave-level inner-node / leaf iterations of the wavefront traversal (lane utilisation =
- * node records / (64 * inner iterations)). */
+ * node records / (64 * inner iterations)); out[7] = lanes without a ray, summed over the inner iterations. */
 int ptr_stats_enable(ptr_ctx* ctx, int on);
 int ptr_stats_read(ptr_ctx* ctx, uint64_t out[8], int reset);
 /* Per-kernel device time from HIP events recorded around every launch on the context's stream. */

@@ -124,6 +124,8 @@ constexpr int32_t kTraversalDone = INT32_MIN;  // never a leaf reference: triang
 //     the two step kinds, the one more lanes are waiting for (leaves are favoured by the factor LEAF_WEIGHT: a
 //     leaf hit shortens the ray and culls later nodes); the other lanes keep their state and wait.  A ray's own
 //     sequence of steps never changes, only when it is executed.
+//   * The grid is the same for every launch of a frame.  Sharing a short queue among fewer waves (so that each keeps
+//     ~300 rays and drains less) was measured: slower at every setting -- parallelism beats lane utilisation here.
 //   * Per-lane stack: kStackLds entries in LDS (lane-interleaved, conflict-free), deeper entries in global memory.
 template <bool STATS, int REFILL, int LEAF_WEIGHT, bool LEAF_ALL, int INNER_REPS>
 __global__ __launch_bounds__(kExtendThreads, 4) void ptr_wf_extend(FlatView fv, WavefrontScratch w, uint32_t gen, uint32_t slot_b,
@@ -143,6 +145,7 @@ __global__ __launch_bounds__(kExtendThreads, 4) void ptr_wf_extend(FlatView fv, 
     uint32_t next_k = 0u;                       // wave-uniform: rays of my list already handed to lanes
     unsigned long long n_rays = 0, n_nodes = 0, n_tris = 0;
     unsigned long long wave_inner_steps = 0, wave_leaf_steps = 0;  // wave-uniform: iterations of each kind
+    unsigned long long idle_lane_steps = 0;                        // wave-uniform: lanes without a ray, summed over inner-step slots
 
     const float min_t = 0.001f;
     uint32_t slot = kInvalidPixel;              // queue slot this lane is tracing; kInvalidPixel = idle
@@ -185,7 +188,10 @@ __global__ __launch_bounds__(kExtendThreads, 4) void ptr_wf_extend(FlatView fv, 
         const uint32_t n_inner = (uint32_t)__popcll(__ballot(at_inner));
         const uint32_t n_leaf = (uint32_t)__popcll(__ballot(at_leaf));
         const bool leaf_turn = n_leaf * (uint32_t)LEAF_WEIGHT > n_inner;
-        if (STATS) { if (leaf_turn) wave_leaf_steps++; else wave_inner_steps += INNER_REPS; }
+        if (STATS) {
+            if (leaf_turn) wave_leaf_steps++;
+            else { wave_inner_steps += INNER_REPS; idle_lane_steps += (unsigned long long)INNER_REPS * (unsigned)__popcll(idle); }
+        }
 
         // kInnerReps 4-wide nodes per inner turn (four box tests each, nearest child next, the others stacked):
         // repeating the step amortises the per-iteration bookkeeping (ballots, refill test, completion)
@@ -284,7 +290,7 @@ __global__ __launch_bounds__(kExtendThreads, 4) void ptr_wf_extend(FlatView fv, 
         }
         if (lane == 0u) {
             atomicAdd(&stats[0], n_rays); atomicAdd(&stats[1], n_nodes); atomicAdd(&stats[2], n_tris);
-            atomicAdd(&stats[5], wave_inner_steps); atomicAdd(&stats[6], wave_leaf_steps);
+            atomicAdd(&stats[5], wave_inner_steps); atomicAdd(&stats[6], wave_leaf_steps); atomicAdd(&stats[7], idle_lane_steps);
         }
     }
 }

@@ -158,7 +158,7 @@ class Context:
         out = (C.c_uint64 * 8)()
         self._check(self._L.ptr_stats_read(self.handle, out, 1 if reset else 0))
         return dict(rays=int(out[0]), nodes=int(out[1]), triangles=int(out[2]), shaded=int(out[3]), frames=int(out[4]),
-                    wave_inner_steps=int(out[5]), wave_leaf_steps=int(out[6]))
+                    wave_inner_steps=int(out[5]), wave_leaf_steps=int(out[6]), idle_lane_steps=int(out[7]))
 
     def profile_enable(self, on):
         self._check(self._L.ptr_profile_enable(self.handle, 1 if on else 0))

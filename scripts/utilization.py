@@ -28,5 +28,6 @@ for mb in range(1, args.bounces + 1):
         st = {k: cur[k] - prev[k] for k in cur}
     prev = cur
     print(f"bounce {mb - 1}: rays {st['rays']} nodes/ray {st['nodes'] / max(1, st['rays']):.1f} tris/ray {st['triangles'] / max(1, st['rays']):.2f} "
-          f"inner util {st['nodes'] / max(1, 64 * st['wave_inner_steps']):.3f} leaf-step lanes {st['wave_leaf_steps']}", flush=True)
+          f"inner util {st['nodes'] / max(1, 64 * st['wave_inner_steps']):.3f} (lanes without a ray {st['idle_lane_steps'] / max(1, 64 * st['wave_inner_steps']):.3f}) "
+          f"leaf turns {st['wave_leaf_steps']}", flush=True)
 ctx.close()
