@@ -85,6 +85,14 @@ int ptr_bvh_bind_flat(ptr_ctx* ctx, ptr_handle threaded_nodes, ptr_handle flat);
  *      constants: the 64-byte push-constant block (compute.comp:109-120): seven device addresses at
  *      0,8,...,48 (scene, bvh, indices, positions, normals, uvs, materials), output image index at 56,
  *      accumulation image index at 60.  groups_*: counts of 8x8x1 workgroups. ---- */
+/* Builds the flattened layout on the GPU from the scene's own device buffers: `indices` (in the layout "scene.index_words"
+ * names) and `positions`, `triangle_count` triangles.  *flat_out is a new buffer (destroy it with ptr_buffer_destroy) ready for
+ * ptr_bvh_bind_flat.  Extends bvh::bvh (src/bvh.cpp:48-86), which builds on one host thread: a Morton-order radix tree collapsed
+ * to the same 4-wide quantised format the host flattener emits -- milliseconds per million triangles, a somewhat slower tree
+ * to traverse than the host's binned-SAH one.  Equal-t ties are broken by primitive id (the host path can carry the reference's
+ * visiting order instead).  Synchronous.  PTR_E_RANGE when the tree would be deeper than the traversal stack. */
+int ptr_bvh_build_flat(ptr_ctx* ctx, ptr_handle indices, ptr_handle positions, uint32_t triangle_count, ptr_handle* flat_out);
+
 int ptr_dispatch(ptr_ctx* ctx, const char* kernel, const uint8_t constants[64], uint32_t groups_x, uint32_t groups_y,
                  uint32_t groups_z);
 

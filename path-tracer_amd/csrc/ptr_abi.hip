@@ -786,6 +786,44 @@ int ptr_bvh_bind_flat(ptr_ctx* c, ptr_handle threaded_nodes, ptr_handle flat) {
     return PTR_OK;
 }
 
+int ptr_bvh_build_flat(ptr_ctx* c, ptr_handle indices, ptr_handle positions, uint32_t triangle_count, ptr_handle* flat_out) {
+    if (!c) return PTR_E_INVALID;
+    if (!flat_out) return fail(c, PTR_E_INVALID, "ptr_bvh_build_flat: flat_out is null");
+    BufferRec* ib = find_buffer(c, indices);
+    BufferRec* pb = find_buffer(c, positions);
+    if (!ib || !pb) return fail(c, PTR_E_INVALID, "ptr_bvh_build_flat: unknown index or position buffer");
+    if (triangle_count == 0) return fail(c, PTR_E_INVALID, "ptr_bvh_build_flat: no triangles");
+    if (triangle_count >= (1u << 29)) return fail(c, PTR_E_RANGE, "ptr_bvh_build_flat: too many triangles for the leaf reference encoding");
+    const size_t index_bytes = (size_t)triangle_count * (size_t)c->opt_index_words * 4;
+    if (ib->size < index_bytes) return fail(c, PTR_E_RANGE, "ptr_bvh_build_flat: the index buffer holds fewer than %u triangles of %d words", triangle_count, c->opt_index_words);
+    const uint64_t vertices = pb->size / 12u;
+    if (vertices == 0) return fail(c, PTR_E_RANGE, "ptr_bvh_build_flat: the position buffer holds no vertex");
+    int rc = bind_device(c); if (rc) return rc;
+    ptr::SceneView sv{};
+    sv.indices = (const uint32_t*)ib->ptr;
+    sv.positions = (const float*)pb->ptr;
+    sv.index_words = (uint32_t)c->opt_index_words;
+    const size_t bytes = ptr::flat_build_blob_bytes(triangle_count);
+    BufferRec b;
+    PTR_HIP_CHECK(c, hipMalloc(&b.ptr, bytes));
+    int status = 0;
+    hipEvent_t t0 = nullptr, t1 = nullptr;
+    if (c->profile_on) { t0 = take_event(c); t1 = take_event(c); if (t0) (void)hipEventRecord(t0, c->stream); }
+    const hipError_t e = ptr::build_flat_bvh(c->stream, sv, triangle_count, (uint32_t)(vertices > 0xffffffffull ? 0xffffffffull : vertices), b.ptr, bytes, &status);
+    if (c->profile_on && t0 && t1) { (void)hipEventRecord(t1, c->stream); c->profile["bvh.build_flat"].pending.emplace_back(t0, t1); }
+    if (e != hipSuccess || status != 0) {
+        (void)hipFree(b.ptr);
+        if (e != hipSuccess) return fail(c, PTR_E_HIP, "ptr_bvh_build_flat: %s", hipGetErrorString(e));
+        return fail(c, status == -5 ? PTR_E_RANGE : PTR_E_STATE, status == -5 ? "ptr_bvh_build_flat: the tree is deeper than the traversal stack (use the host builder)"
+                                                                                : "ptr_bvh_build_flat: the tree could not be built (status %d)", status);
+    }
+    b.size = bytes; b.alive = true;
+    b.generation = ++c->write_epoch;
+    c->buffers.push_back(std::move(b));
+    *flat_out = (ptr_handle)(c->buffers.size() - 1);
+    return PTR_OK;
+}
+
 int ptr_dispatch(ptr_ctx* c, const char* kernel, const uint8_t constants[64], uint32_t gx, uint32_t gy, uint32_t gz) {
     if (!c) return PTR_E_INVALID;
     if (!kernel || !constants) return fail(c, PTR_E_INVALID, "ptr_dispatch: null kernel name or constants");

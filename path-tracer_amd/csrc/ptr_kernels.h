@@ -58,6 +58,12 @@ hipError_t launch_wf_shade(hipStream_t s, const SceneView& sv, const WavefrontSc
 hipError_t launch_wf_build_shade_records(hipStream_t s, const SceneView& sv, uint32_t triangle_count, uint32_t vertex_count, float4* records);
 hipError_t launch_wf_accumulate(hipStream_t s, const SceneView& sv, const WavefrontScratch& w, uint32_t domain_w, uint32_t domain_h);
 
+// GPU construction of the flattened BVH (ptr_kernels_build.hip) from the index / position buffers of `sv` into `blob`
+// (flat_build_blob_bytes(n) bytes of device memory).  Synchronous.  *status: 0 ok, < 0 = why the tree could not be built
+// (-1 bad arguments, -3 node capacity or quantisation, -5 deeper than the traversal stack, others internal).
+size_t flat_build_blob_bytes(uint32_t triangle_count);
+hipError_t build_flat_bvh(hipStream_t s, const SceneView& sv, uint32_t triangle_count, uint32_t vertex_count, void* blob, size_t blob_bytes, int* status);
+
 // Per-function test kernel (ptr_kernels_unit.hip): index of `name` (< 0 if unknown) with its record sizes in 32-bit words.
 int unit_function_lookup(const char* name, uint32_t* in_words, uint32_t* out_words);
 hipError_t launch_unit_function(hipStream_t s, int fn, const uint32_t* in, uint32_t in_words, uint32_t* out, uint32_t out_words, uint32_t count);

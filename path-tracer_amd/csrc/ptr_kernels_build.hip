@@ -1,0 +1,411 @@
+// GPU construction of the flattened 4-wide BVH (the layout of host/bvh.hpp, version 2) straight from the scene's
+// device buffers: Morton order -> radix tree (Karras 2012) -> bottom-up boxes -> top-down collapse to 4-wide nodes
+// with quantised child boxes.  It trades tree quality for build time (milliseconds instead of a second per few
+// million triangles on the host's binned-SAH builder); the traversal kernels cannot tell the two apart.
+//
+//   1. per triangle: box and centroid; scene box by block reduction + ordered-integer atomics
+//   2. 63-bit Morton key of the centroid (21 bits per axis), radix sort of (key, triangle) pairs (hipCUB)
+//   3. binary radix tree over the sorted keys, ties broken by position; parents recorded
+//   4. boxes bottom-up: the second thread to reach a node merges its children and goes on
+//   5. leaves: subtrees of at most 4 triangles (contiguous in sorted order, so triangle records are simply written
+//      in sorted order); wide nodes level by level from the root: a node adopts its two children and keeps replacing
+//      the inner child of largest surface area by that child's children until it has four
+#pragma clang fp contract(off)
+
+#include <hipcub/hipcub.hpp>
+
+#include <cstring>
+
+#include "ptr_kernels.h"
+
+namespace ptr {
+
+namespace {
+
+constexpr int32_t kEmptyChildRef = INT32_MIN;
+constexpr uint32_t kLeafMax = 4;
+
+struct BuildNode {      // one internal node of the binary radix tree
+    int32_t left, right;       // >= 0: internal node, < 0: ~sorted position of a single triangle
+    uint32_t first, last;      // range of sorted positions covered
+    float lo[3], hi[3];
+};
+
+struct Frontier { uint32_t node, wide, pending; };
+
+// order-preserving float <-> uint mapping for atomicMin / atomicMax
+PTR_DEV uint32_t ordered(float f) { const uint32_t u = __float_as_uint(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
+PTR_DEV float unordered(uint32_t u) { return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u); }
+
+PTR_DEV void triangle_corners(const SceneView& sv, uint32_t tri, uint32_t vertex_count, f3& p0, f3& p1, f3& p2) {
+    uint32_t i0, i1, i2, mat;
+    decode_triangle(sv, tri, i0, i1, i2, mat);
+    const uint32_t last = vertex_count - 1u;
+    i0 = i0 < last ? i0 : last; i1 = i1 < last ? i1 : last; i2 = i2 < last ? i2 : last;
+    p0 = load3(sv.positions, i0); p1 = load3(sv.positions, i1); p2 = load3(sv.positions, i2);
+}
+
+// ---- 1. boxes + scene bounds ------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void build_boxes(SceneView sv, uint32_t n, uint32_t vertex_count, float4* box_lo, float4* box_hi, uint32_t* scene) {
+    __shared__ uint32_t red[6];
+    if (threadIdx.x < 3) red[threadIdx.x] = 0xffffffffu; else if (threadIdx.x < 6) red[threadIdx.x] = 0u;
+    __syncthreads();
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i < n) {
+        f3 a, b, c;
+        triangle_corners(sv, i, vertex_count, a, b, c);
+        const f3 lo = mk3(min_num(min_num(a.x, b.x), c.x), min_num(min_num(a.y, b.y), c.y), min_num(min_num(a.z, b.z), c.z));
+        const f3 hi = mk3(max_num(max_num(a.x, b.x), c.x), max_num(max_num(a.y, b.y), c.y), max_num(max_num(a.z, b.z), c.z));
+        box_lo[i] = make_float4(lo.x, lo.y, lo.z, 0.f);
+        box_hi[i] = make_float4(hi.x, hi.y, hi.z, 0.f);
+        atomicMin(&red[0], ordered(lo.x)); atomicMin(&red[1], ordered(lo.y)); atomicMin(&red[2], ordered(lo.z));
+        atomicMax(&red[3], ordered(hi.x)); atomicMax(&red[4], ordered(hi.y)); atomicMax(&red[5], ordered(hi.z));
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) atomicMin(&scene[threadIdx.x], red[threadIdx.x]);
+    else if (threadIdx.x < 6) atomicMax(&scene[threadIdx.x], red[threadIdx.x]);
+}
+
+// ---- 2. Morton keys ----------------------------------------------------------------------------------------
+PTR_DEV uint64_t spread21(uint32_t v) {  // 21 bits -> every third bit of 63
+    uint64_t x = v & 0x1fffffu;
+    x = (x | (x << 32)) & 0x1f00000000ffffull;
+    x = (x | (x << 16)) & 0x1f0000ff0000ffull;
+    x = (x | (x << 8)) & 0x100f00f00f00f00full;
+    x = (x | (x << 4)) & 0x10c30c30c30c30c3ull;
+    x = (x | (x << 2)) & 0x1249249249249249ull;
+    return x;
+}
+__global__ __launch_bounds__(256) void build_keys(uint32_t n, const float4* box_lo, const float4* box_hi, const uint32_t* scene, uint64_t* keys, uint32_t* vals) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const float4 lo = box_lo[i], hi = box_hi[i];
+    const float smin[3] = { unordered(scene[0]), unordered(scene[1]), unordered(scene[2]) };
+    const float smax[3] = { unordered(scene[3]), unordered(scene[4]), unordered(scene[5]) };
+    const float c[3] = { 0.5f * lo.x + 0.5f * hi.x, 0.5f * lo.y + 0.5f * hi.y, 0.5f * lo.z + 0.5f * hi.z };
+    uint32_t q[3];
+    for (int a = 0; a < 3; a++) {
+        const float extent = smax[a] - smin[a];
+        float t = extent > 0.f ? (c[a] - smin[a]) / extent : 0.f;
+        t = t >= 0.f ? t : 0.f;                       // also catches NaN
+        const float s = t * 2097152.0f;
+        q[a] = s >= 2097151.0f ? 2097151u : (uint32_t)s;
+    }
+    keys[i] = (spread21(q[0]) << 2) | (spread21(q[1]) << 1) | spread21(q[2]);
+    vals[i] = i;
+}
+
+// ---- 3. radix tree -----------------------------------------------------------------------------------------
+// common-prefix length of the (key, position) pairs at sorted positions i and j; -1 when j is out of range
+PTR_DEV int prefix(const uint64_t* keys, uint32_t n, int64_t i, int64_t j) {
+    if (j < 0 || j >= (int64_t)n) return -1;
+    const uint64_t a = keys[i], b = keys[j];
+    if (a != b) return __clzll((long long)(a ^ b));
+    return 64 + __clz((int)((uint32_t)i ^ (uint32_t)j));
+}
+__global__ __launch_bounds__(256) void build_tree(uint32_t n, const uint64_t* keys, BuildNode* nodes, int32_t* node_parent, int32_t* leaf_parent) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (int64_t)n - 1) return;
+    const int d = prefix(keys, n, i, i + 1) - prefix(keys, n, i, i - 1) >= 0 ? 1 : -1;
+    const int dmin = prefix(keys, n, i, i - d);
+    int64_t lmax = 2;
+    while (prefix(keys, n, i, i + lmax * d) > dmin) lmax *= 2;
+    int64_t l = 0;
+    for (int64_t t = lmax / 2; t >= 1; t /= 2)
+        if (prefix(keys, n, i, i + (l + t) * d) > dmin) l += t;
+    const int64_t j = i + l * d;
+    const int dnode = prefix(keys, n, i, j);
+    int64_t s = 0;
+    for (int64_t t = l;;) {
+        t = (t + 1) / 2;
+        if (prefix(keys, n, i, i + (s + t) * d) > dnode) s += t;
+        if (t <= 1) break;
+    }
+    const int64_t gamma = i + s * d + (d < 0 ? -1 : 0);
+    const int64_t first = i < j ? i : j, last = i < j ? j : i;
+    BuildNode& nd = nodes[i];
+    nd.first = (uint32_t)first; nd.last = (uint32_t)last;
+    if (first == gamma) { nd.left = ~(int32_t)gamma; leaf_parent[gamma] = (int32_t)i; }
+    else { nd.left = (int32_t)gamma; node_parent[gamma] = (int32_t)i; }
+    if (last == gamma + 1) { nd.right = ~(int32_t)(gamma + 1); leaf_parent[gamma + 1] = (int32_t)i; }
+    else { nd.right = (int32_t)(gamma + 1); node_parent[gamma + 1] = (int32_t)i; }
+    if (i == 0) node_parent[0] = -1;
+}
+
+// ---- 4. boxes bottom-up + triangle records (written in sorted order) ---------------------------------------
+__global__ __launch_bounds__(256) void build_fit(SceneView sv, uint32_t n, uint32_t vertex_count, const uint32_t* vals, const float4* box_lo,
+                                                 const float4* box_hi, BuildNode* nodes, const int32_t* node_parent, const int32_t* leaf_parent,
+                                                 uint32_t* visits, float4* out_tris) {
+    const uint32_t p = blockIdx.x * 256u + threadIdx.x;
+    if (p >= n) return;
+    const uint32_t tri = vals[p];
+    {
+        f3 a, b, c;
+        triangle_corners(sv, tri, vertex_count, a, b, c);
+        const f3 e1 = b - a, e2 = c - a;
+        const f3 nrm = cross(e1, e2);  // = (e1.y*e2.z - e2.y*e1.z, ...), the shader's operation order (ray.h:142-146)
+        float4* rec = out_tris + 4 * (size_t)p;
+        rec[0] = make_float4(a.x, a.y, a.z, __int_as_float((int32_t)tri));   // rank = primitive id: no reference order on the GPU
+        rec[1] = make_float4(e1.x, e1.y, e1.z, __int_as_float((int32_t)tri));
+        rec[2] = make_float4(e2.x, e2.y, e2.z, 0.f);
+        rec[3] = make_float4(nrm.x, nrm.y, nrm.z, 0.f);
+    }
+    if (n == 1) return;
+    int32_t node = leaf_parent[p];
+    while (node >= 0) {
+        __threadfence();
+        if (atomicAdd(&visits[node], 1u) == 0u) return;  // the sibling subtree is not finished: its thread will continue
+        __threadfence();
+        BuildNode& nd = nodes[node];
+        float lo[3], hi[3];
+        for (int side = 0; side < 2; side++) {
+            const int32_t c = side ? nd.right : nd.left;
+            float clo[3], chi[3];
+            if (c < 0) {
+                const uint32_t t = vals[(uint32_t)~c];
+                const float4 l4 = box_lo[t], h4 = box_hi[t];
+                clo[0] = l4.x; clo[1] = l4.y; clo[2] = l4.z; chi[0] = h4.x; chi[1] = h4.y; chi[2] = h4.z;
+            } else {
+                const volatile BuildNode& cn = nodes[c];
+                for (int a = 0; a < 3; a++) { clo[a] = cn.lo[a]; chi[a] = cn.hi[a]; }
+            }
+            for (int a = 0; a < 3; a++) {
+                lo[a] = side ? min_num(lo[a], clo[a]) : clo[a];
+                hi[a] = side ? max_num(hi[a], chi[a]) : chi[a];
+            }
+        }
+        for (int a = 0; a < 3; a++) { nd.lo[a] = lo[a]; nd.hi[a] = hi[a]; }
+        node = node_parent[node];
+    }
+}
+
+// ---- 5. collapse + quantise --------------------------------------------------------------------------------
+struct ChildBox { float lo[3], hi[3]; };
+
+PTR_DEV float step_from_biased(int biased) { return __uint_as_float((uint32_t)biased << 23); }
+
+// Origin, power-of-two step and quantised [lo, hi] of one axis; the same rule as the host flattener:
+// decoded lo <= true lo - margin and decoded hi >= true hi + margin, margin = 2^-20 of the node extent.
+PTR_DEV bool quantise_axis(float node_lo, float node_hi, const float* lo, const float* hi, uint32_t count, float& origin, float& step, uint32_t& qlo, uint32_t& qhi) {
+    const float extent = node_hi - node_lo;
+    const float margin = max_num(extent * 9.5367431640625e-07f, 1e-30f);
+    origin = nextafterf(node_lo - margin, -__builtin_inff());
+    const float span = (node_hi + margin) - origin;
+    int e;
+    {
+        const double per = (double)span / 255.0;
+        int ex = 0;
+        (void)frexp(per, &ex);                      // per = m * 2^ex, m in [0.5, 1)
+        e = ex < -126 ? -126 : (ex > 127 ? 127 : ex);
+    }
+    for (;; e++) {
+        if (e > 127) return false;
+        const float st = step_from_biased(e + 127);
+        bool ok = true;
+        uint32_t pl = 0, ph = 0;
+        for (uint32_t k = 0; k < count && ok; k++) {
+            const float want_lo = lo[k] - margin, want_hi = hi[k] + margin;
+            double ql = floor(((double)want_lo - (double)origin) / (double)st);
+            ql = ql < 0.0 ? 0.0 : (ql > 255.0 ? 255.0 : ql);
+            uint32_t a = (uint32_t)ql;
+            while (a > 0u && origin + (float)a * st > want_lo) a--;
+            double qh = ceil(((double)want_hi - (double)origin) / (double)st);
+            qh = qh < 0.0 ? 0.0 : (qh > 255.0 ? 255.0 : qh);
+            uint32_t b = (uint32_t)qh;
+            while (b < 255u && origin + (float)b * st < want_hi) b++;
+            if (origin + (float)a * st > want_lo || origin + (float)b * st < want_hi) { ok = false; break; }
+            pl |= a << (8u * k); ph |= b << (8u * k);
+        }
+        if (ok) { step = st; qlo = pl; qhi = ph; return true; }
+    }
+}
+
+// One wide node per frontier entry.  counters: [0] wide nodes allocated, [1] next frontier length, [2] stack need, [3] failure flag.
+__global__ __launch_bounds__(128) void build_collapse(uint32_t count, const Frontier* in, Frontier* out, const BuildNode* nodes, const uint32_t* vals,
+                                                      const float4* box_lo, const float4* box_hi, float4* out_nodes, uint32_t* counters,
+                                                      uint32_t node_capacity) {
+    const uint32_t f = blockIdx.x * 128u + threadIdx.x;
+    if (f >= count) return;
+    const Frontier item = in[f];
+    auto is_inner = [&](int32_t c) { return c >= 0 && nodes[c].last - nodes[c].first + 1u > kLeafMax; };
+    auto box_of = [&](int32_t c, ChildBox& b) {
+        if (c < 0) {
+            const uint32_t t = vals[(uint32_t)~c];
+            const float4 l4 = box_lo[t], h4 = box_hi[t];
+            b.lo[0] = l4.x; b.lo[1] = l4.y; b.lo[2] = l4.z; b.hi[0] = h4.x; b.hi[1] = h4.y; b.hi[2] = h4.z;
+        } else {
+            for (int a = 0; a < 3; a++) { b.lo[a] = nodes[c].lo[a]; b.hi[a] = nodes[c].hi[a]; }
+        }
+    };
+    const BuildNode& self = nodes[item.node];
+    int32_t child[4] = { self.left, self.right, 0, 0 };
+    uint32_t n_children = 2;
+    while (n_children < 4u) {
+        int best = -1;
+        float best_area = -1.f;
+        for (uint32_t k = 0; k < n_children; k++) {
+            if (!is_inner(child[k])) continue;
+            const BuildNode& c = nodes[child[k]];
+            const float dx = c.hi[0] - c.lo[0], dy = c.hi[1] - c.lo[1], dz = c.hi[2] - c.lo[2];
+            const float area = 2.f * (dx * dy + dy * dz + dz * dx);
+            if (area > best_area) { best_area = area; best = (int)k; }
+        }
+        if (best < 0) break;
+        const BuildNode& c = nodes[child[best]];
+        child[best] = c.left;
+        child[n_children++] = c.right;
+    }
+    const uint32_t pending = item.pending + (n_children - 1u);
+    atomicMax(&counters[2], pending);
+
+    ChildBox boxes[4];
+    int32_t refs[4] = { kEmptyChildRef, kEmptyChildRef, kEmptyChildRef, kEmptyChildRef };
+    for (uint32_t k = 0; k < n_children; k++) {
+        box_of(child[k], boxes[k]);
+        if (is_inner(child[k])) {
+            const uint32_t w = atomicAdd(&counters[0], 1u);
+            if (w >= node_capacity) { counters[3] = 1u; return; }
+            const uint32_t slot = atomicAdd(&counters[1], 1u);
+            Frontier next; next.node = (uint32_t)child[k]; next.wide = w; next.pending = pending;
+            out[slot] = next;
+            refs[k] = (int32_t)w;
+        } else if (child[k] < 0) {
+            refs[k] = ~(int32_t)((((uint32_t)~child[k]) << 2) | 0u);
+        } else {
+            const BuildNode& c = nodes[child[k]];
+            refs[k] = ~(int32_t)((c.first << 2) | (c.last - c.first));
+        }
+    }
+    float origin[3], step[3];
+    uint32_t qlo[3], qhi[3];
+    for (int a = 0; a < 3; a++) {
+        float lo[4], hi[4];
+        for (uint32_t k = 0; k < n_children; k++) { lo[k] = boxes[k].lo[a]; hi[k] = boxes[k].hi[a]; }
+        if (!quantise_axis(self.lo[a], self.hi[a], lo, hi, n_children, origin[a], step[a], qlo[a], qhi[a])) { counters[3] = 2u; return; }
+    }
+    float4* nd = out_nodes + 4 * (size_t)item.wide;
+    nd[0] = make_float4(origin[0], origin[1], origin[2], step[0]);
+    nd[1] = make_float4(__int_as_float(refs[0]), __int_as_float(refs[1]), __int_as_float(refs[2]), __int_as_float(refs[3]));
+    nd[2] = make_float4(__uint_as_float(qlo[0]), __uint_as_float(qlo[1]), __uint_as_float(qlo[2]), __uint_as_float(qhi[0]));
+    nd[3] = make_float4(__uint_as_float(qhi[1]), __uint_as_float(qhi[2]), step[1], step[2]);
+}
+
+struct FlatHeader {
+    uint32_t magic, version, node_count, triangle_count;
+    uint64_t nodes_offset, triangles_offset;
+    int32_t root; uint32_t max_depth;
+    float scene_min[3], scene_max[3];
+};
+static_assert(sizeof(FlatHeader) == 64, "header is one 64-byte line");
+
+#define BUILD_CHECK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { cleanup(); return e_; } } while (0)
+
+}  // namespace
+
+size_t flat_build_blob_bytes(uint32_t triangle_count) {
+    // header + at most one wide node per two triangles' worth of leaves... a wide node has >= 2 children, so there are
+    // fewer wide nodes than leaves, and no more leaves than triangles
+    return 64 + (size_t)triangle_count * 64 + (size_t)triangle_count * 64;
+}
+
+hipError_t build_flat_bvh(hipStream_t s, const SceneView& sv, uint32_t n, uint32_t vertex_count, void* blob, size_t blob_bytes, int* status) {
+    *status = 0;
+    if (n == 0 || vertex_count == 0 || blob_bytes < flat_build_blob_bytes(n)) { *status = -1; return hipSuccess; }
+    const uint32_t node_capacity = n;
+    void* pool[12] = {};
+    int pooled = 0;
+    auto cleanup = [&]() { for (int i = 0; i < pooled; i++) (void)hipFree(pool[i]); };
+    auto take = [&](size_t bytes, void** out) -> hipError_t {
+        hipError_t e = hipMalloc(out, bytes ? bytes : 16);
+        if (e == hipSuccess) pool[pooled++] = *out;
+        return e;
+    };
+    float4 *box_lo = nullptr, *box_hi = nullptr;
+    uint64_t *keys = nullptr, *keys_sorted = nullptr;
+    uint32_t *vals = nullptr, *vals_sorted = nullptr, *scene = nullptr, *visits = nullptr, *counters = nullptr;
+    BuildNode* nodes = nullptr;
+    int32_t *node_parent = nullptr, *leaf_parent = nullptr;
+    Frontier* frontier[2] = { nullptr, nullptr };
+    void* sort_temp = nullptr;
+    BUILD_CHECK(take((size_t)n * 16, (void**)&box_lo));
+    BUILD_CHECK(take((size_t)n * 16, (void**)&box_hi));
+    BUILD_CHECK(take((size_t)n * 8, (void**)&keys));
+    BUILD_CHECK(take((size_t)n * 8, (void**)&keys_sorted));
+    BUILD_CHECK(take((size_t)n * 4, (void**)&vals));
+    BUILD_CHECK(take((size_t)n * 4, (void**)&vals_sorted));
+    BUILD_CHECK(take(64, (void**)&scene));
+    BUILD_CHECK(take((size_t)n * sizeof(BuildNode), (void**)&nodes));
+    BUILD_CHECK(take((size_t)n * 4 * 3, (void**)&node_parent));   // node_parent | leaf_parent | visits
+    leaf_parent = node_parent + n;
+    visits = (uint32_t*)(node_parent + 2 * (size_t)n);
+    counters = scene + 8;
+
+    const uint32_t init[16] = { 0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u, 0u, 0u, /* counters */ 1u, 0u, 0u, 0u, 0u, 0u, 0u, 0u };
+    BUILD_CHECK(hipMemcpyAsync(scene, init, sizeof init, hipMemcpyHostToDevice, s));
+    BUILD_CHECK(hipMemsetAsync(visits, 0, (size_t)n * 4, s));
+    const uint32_t blocks = (n + 255u) / 256u;
+    hipLaunchKernelGGL(build_boxes, dim3(blocks), dim3(256), 0, s, sv, n, vertex_count, box_lo, box_hi, scene);
+    hipLaunchKernelGGL(build_keys, dim3(blocks), dim3(256), 0, s, n, box_lo, box_hi, scene, keys, vals);
+    size_t temp_bytes = 0;
+    BUILD_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, temp_bytes, keys, keys_sorted, vals, vals_sorted, (int)n, 0, 63, s));
+    BUILD_CHECK(take(temp_bytes, &sort_temp));
+    BUILD_CHECK(hipcub::DeviceRadixSort::SortPairs(sort_temp, temp_bytes, keys, keys_sorted, vals, vals_sorted, (int)n, 0, 63, s));
+
+    uint8_t* out = (uint8_t*)blob;
+    float4* out_nodes = (float4*)(out + 64);
+    float4* out_tris = (float4*)(out + 64 + (size_t)node_capacity * 64);
+    if (n > 1) hipLaunchKernelGGL(build_tree, dim3((n - 1 + 255u) / 256u), dim3(256), 0, s, n, keys_sorted, nodes, node_parent, leaf_parent);
+    hipLaunchKernelGGL(build_fit, dim3(blocks), dim3(256), 0, s, sv, n, vertex_count, vals_sorted, box_lo, box_hi, nodes, node_parent, leaf_parent, visits, out_tris);
+    BUILD_CHECK(hipGetLastError());
+
+    FlatHeader hd{};
+    hd.magic = 0x46525450u; hd.version = 2u; hd.triangle_count = n;
+    hd.nodes_offset = 64; hd.triangles_offset = 64 + (uint64_t)node_capacity * 64;
+    uint32_t host_scene[16];
+    if (n <= kLeafMax) {
+        hd.root = ~(int32_t)((0u << 2) | (n - 1u));
+        hd.node_count = 0; hd.max_depth = 0;
+        BUILD_CHECK(hipMemcpyAsync(host_scene, scene, sizeof host_scene, hipMemcpyDeviceToHost, s));
+        BUILD_CHECK(hipStreamSynchronize(s));
+    } else {
+        // frontier buffers: at most one entry per wide node of a level; reuse the key arrays' storage is not possible
+        // (keys_sorted is still read), so two fresh ones sized by the worst level (every leaf group's parent)
+        BUILD_CHECK(take((size_t)(n / 2 + 2) * sizeof(Frontier), (void**)&frontier[0]));
+        BUILD_CHECK(take((size_t)(n / 2 + 2) * sizeof(Frontier), (void**)&frontier[1]));
+        const Frontier root{ 0u, 0u, 0u };
+        BUILD_CHECK(hipMemcpyAsync(frontier[0], &root, sizeof root, hipMemcpyHostToDevice, s));
+        uint32_t level_count = 1;
+        int cur = 0;
+        for (int level = 0; level_count > 0; level++) {
+            if (level > 4096) { *status = -2; cleanup(); return hipSuccess; }
+            BUILD_CHECK(hipMemsetAsync(counters + 1, 0, 4, s));
+            hipLaunchKernelGGL(build_collapse, dim3((level_count + 127u) / 128u), dim3(128), 0, s, level_count, frontier[cur], frontier[cur ^ 1], nodes,
+                               vals_sorted, box_lo, box_hi, out_nodes, counters, node_capacity);
+            BUILD_CHECK(hipGetLastError());
+            BUILD_CHECK(hipMemcpyAsync(host_scene, scene, sizeof host_scene, hipMemcpyDeviceToHost, s));
+            BUILD_CHECK(hipStreamSynchronize(s));
+            if (host_scene[8 + 3] != 0u) { *status = -3; cleanup(); return hipSuccess; }
+            level_count = host_scene[8 + 1];
+            if (level_count > n / 2 + 2) { *status = -4; cleanup(); return hipSuccess; }
+            cur ^= 1;
+        }
+        hd.root = 0;
+        hd.node_count = host_scene[8 + 0];
+        hd.max_depth = host_scene[8 + 2];
+        if (hd.max_depth > kStackLds + kStackSpill - 2u) { *status = -5; cleanup(); return hipSuccess; }
+    }
+    // scene box: decode the ordered integers on the host
+    for (int a = 0; a < 6; a++) {
+        const uint32_t u = host_scene[a];
+        const uint32_t bits = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u;
+        float f;
+        memcpy(&f, &bits, 4);
+        (a < 3 ? hd.scene_min[a] : hd.scene_max[a - 3]) = f;
+    }
+    BUILD_CHECK(hipMemcpyAsync(out, &hd, sizeof hd, hipMemcpyHostToDevice, s));
+    BUILD_CHECK(hipStreamSynchronize(s));
+    cleanup();
+    return hipSuccess;
+}
+
+}  // namespace ptr

@@ -70,6 +70,7 @@ def lib():
         "ptr_profile_read": [vp, C.c_char_p, P(u64), P(C.c_double), C.c_int],
         "ptr_profile_names": [vp, C.c_char_p, sz],
         "ptr_device_function": [vp, C.c_char_p, vp, u32, vp, u32, u32],
+        "ptr_bvh_build_flat": [vp, u32, u32, u32, P(u32)],
     }
     for name, args in sigs.items():
         fn = getattr(L, name)
@@ -86,7 +87,7 @@ ABI_SYMBOLS = ["ptr_ctx_create", "ptr_ctx_destroy", "ptr_ctx_set_stream", "ptr_l
                "ptr_image_create", "ptr_image_wrap", "ptr_image_destroy", "ptr_image_upload", "ptr_image_read",
                "ptr_image_index", "ptr_sampler_index", "ptr_image_address", "ptr_bvh_bind_flat", "ptr_dispatch",
                "ptr_set_partition", "ptr_set_sample_partition", "ptr_set_option", "ptr_set_capture", "ptr_stats_enable", "ptr_stats_read", "ptr_profile_enable",
-               "ptr_profile_read", "ptr_profile_names", "ptr_device_function"]
+               "ptr_profile_read", "ptr_profile_names", "ptr_device_function", "ptr_bvh_build_flat"]
 
 
 class Context:
@@ -183,6 +184,12 @@ class Context:
         self._check(self._L.ptr_device_function(self.handle, name.encode(), a.ctypes.data, a.shape[1], out.ctypes.data, out_words, a.shape[0]))
         return out
 
+    def build_flat(self, indices_buffer, positions_buffer, triangle_count):
+        """GPU build of the flattened BVH from the scene's device buffers; returns the new Buffer."""
+        h = C.c_uint32()
+        self._check(self._L.ptr_bvh_build_flat(self.handle, indices_buffer.handle, positions_buffer.handle, triangle_count, C.byref(h)))
+        return Buffer.adopt(self, h.value, 64 + 128 * triangle_count)
+
     def bind_flat(self, node_buffer, flat_buffer):
         self._check(self._L.ptr_bvh_bind_flat(self.handle, node_buffer.handle, flat_buffer.handle if flat_buffer is not None else 0))
 
@@ -199,6 +206,13 @@ class Buffer:
         ctx._check(ctx._L.ptr_buffer_create(ctx.handle, size, C.byref(h)))
         self.handle = h.value
         self.buffer_size = size
+
+    @classmethod
+    def adopt(cls, ctx, handle, size=None):
+        """A buffer the library created itself (ptr_bvh_build_flat)."""
+        b = cls.__new__(cls)
+        b.ctx, b.handle, b.buffer_size = ctx, handle, size
+        return b
 
     def write(self, data, alloc_offset=0, data_size=None):
         a = np.ascontiguousarray(data)

@@ -72,3 +72,83 @@ def gpu_frames(ctx, bundle, spp, pipeline, gpu_scene=None, capture=False, stats=
         ctx.set_capture(None)
         cap_buf.destroy()
     return img, gs, cap, st
+
+
+# ---- flattened-layout checker (host builder and GPU builder emit the same format) ----
+def parse(flat):
+    h = host.flat_header(flat)
+    nodes = flat[h["nodes_offset"]:h["nodes_offset"] + 64 * h["node_count"]].view(np.float32).reshape(-1, 16)
+    tris = flat[h["triangles_offset"]:h["triangles_offset"] + 64 * h["triangle_count"]].view(np.float32).reshape(-1, 16)
+    return h, nodes, tris
+
+
+def check_flat_layout(flat, triangles, ranks, tight=True):
+    """Structural invariants of a flattened layout over `triangles` ((N, 9) float32); `ranks` = expected tie-break ranks.
+    tight=False drops the two-step tightness bound (a builder may quantise more loosely, never less conservatively)."""
+    b = dict(flat=flat, triangles=np.asarray(triangles, np.float32).reshape(-1, 9), ranks=np.asarray(ranks))
+    h, nodes, tris = parse(b["flat"])
+    n = b["triangles"].shape[0]
+    assert h["magic"] == 0x46525450 and h["version"] == 2 and h["triangle_count"] == n
+    assert h["nodes_offset"] % 64 == 0 and h["triangles_offset"] % 64 == 0 and b["flat"].nbytes >= 64 + 64 * (h["node_count"] + n)
+    ti = tris.view(np.int32)
+    assert sorted(ti[:, 7].tolist()) == list(range(n))                        # every primitive exactly once
+    assert np.array_equal(ti[:, 3], b["ranks"][ti[:, 7]])                      # rank travels with the primitive
+    tri = b["triangles"].reshape(n, 3, 3)[ti[:, 7]]
+    assert np.array_equal(tris[:, 0:3], tri[:, 0])                             # p0, e1, e2, n = cross(e1, e2) in fp32
+    e1, e2 = tri[:, 1] - tri[:, 0], tri[:, 2] - tri[:, 0]
+    assert np.array_equal(tris[:, 4:7], e1) and np.array_equal(tris[:, 8:11], e2)
+    nrm = np.stack([e1[:, 1] * e2[:, 2] - e2[:, 1] * e1[:, 2], e1[:, 2] * e2[:, 0] - e2[:, 2] * e1[:, 0],
+                    e1[:, 0] * e2[:, 1] - e2[:, 0] * e1[:, 1]], 1)
+    assert np.array_equal(tris[:, 12:15], nrm)
+
+    # walk the 4-wide tree: every decoded child box contains its subtree (conservative quantisation, within one
+    # step of the true bound), leaves hold 1..4 triangles and tile the triangle array, the stack bound holds
+    ni = nodes.view(np.int32)
+    nu = nodes.view(np.uint32)
+    seen = np.zeros(n, bool)
+    tmin, tmax = tri.min(axis=1), tri.max(axis=1)
+    EMPTY = -2 ** 31
+    worst_stack = 0
+
+    def bounds_of(ref, pending):
+        nonlocal worst_stack
+        if ref < 0:
+            first, cnt = (~ref) >> 2, ((~ref) & 3) + 1
+            assert not seen[first:first + cnt].any()
+            seen[first:first + cnt] = True
+            return tmin[first:first + cnt].min(axis=0), tmax[first:first + cnt].max(axis=0)
+        nd = nodes[ref]
+        count = sum(1 for k in range(4) if int(ni[ref, 4 + k]) != EMPTY)
+        assert 2 <= count <= 4
+        step = np.array([nd[3], nd[14], nd[15]], dtype=np.float32)
+        assert all(float(x) > 0 and np.frexp(x)[0] == 0.5 for x in step), "steps are powers of two"
+        worst_stack = max(worst_stack, pending + count - 1)
+        lo_all, hi_all = [], []
+        for k in range(4):
+            child = int(ni[ref, 4 + k])
+            if k >= count:
+                assert child == EMPTY
+                continue
+            assert child != EMPTY
+            qlo = np.array([(int(nu[ref, 8 + a]) >> (8 * k)) & 0xFF for a in range(3)], dtype=np.float32)
+            qhi = np.array([(int(nu[ref, 11 + a]) >> (8 * k)) & 0xFF for a in range(3)], dtype=np.float32)  # words 11, 12, 13
+            dlo = nd[0:3] + qlo * step
+            dhi = nd[0:3] + qhi * step
+            lo, hi = bounds_of(child, pending + count - 1)
+            assert (dlo <= lo).all() and (dhi >= hi).all(), "decoded box must contain the subtree"
+            if tight:
+                assert (lo - dlo <= step * 2.001 + 1e-30).all() and (dhi - hi <= step * 2.001 + 1e-30).all(), "and be tight to two steps"
+            lo_all.append(lo); hi_all.append(hi)
+        lo, hi = np.min(lo_all, axis=0), np.max(hi_all, axis=0)
+        slack = (hi - lo) * 2e-6 + 2 * np.spacing(np.abs(lo).astype(np.float32)) + 1e-29
+        assert (nd[0:3] < lo).all() and (lo - nd[0:3] <= slack).all(), "node origin sits a margin below the true box minimum"
+        return lo, hi
+
+    import sys
+    sys.setrecursionlimit(10000)
+    lo, hi = bounds_of(h["root"], 0)
+    assert seen.all() and worst_stack <= h["max_depth"] <= 62
+    assert np.array_equal(lo, h["scene_min"]) and np.array_equal(hi, h["scene_max"])
+    return h
+
+

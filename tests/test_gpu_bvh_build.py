@@ -1,0 +1,89 @@
+"""The GPU builder of the flattened BVH (ptr_bvh_build_flat): its output obeys the layout's invariants (the same
+checker as for the host flattener), and frames traced through it equal the CPU oracle walking the very same blob."""
+import numpy as np
+import pytest
+
+from common import check_flat_layout, gpu_frames, make_bundle, oracle_frames
+from path_tracer_amd import scenes
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from path_tracer_amd import hip
+    c = hip.Context(0)
+    yield c
+    c.close()
+
+
+def build_from_triangles(ctx, tri):
+    """tri: (N, 9) float32 -> flattened blob built on the GPU from an index + position buffer pair."""
+    tri = np.ascontiguousarray(tri, np.float32).reshape(-1, 9)
+    n = tri.shape[0]
+    idx = ctx.create_buffer(max(16, n * 12))
+    pos = ctx.create_buffer(max(16, n * 36))
+    idx.write(np.arange(3 * n, dtype=np.uint32))       # material byte 0 on every word: plain vertex ids
+    pos.write(tri.reshape(-1))
+    ctx.set_option("scene.index_words", 3)
+    flat = ctx.build_flat(idx, pos, n)
+    blob = flat.read(np.uint8)
+    for b in (idx, pos, flat):
+        b.destroy()
+    return blob
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 4, 5, 9, 33, 1000])
+def test_small_inputs(ctx, n):
+    rng = np.random.default_rng(n)
+    tri = rng.random((n, 9), dtype=np.float32)
+    h = check_flat_layout(build_from_triangles(ctx, tri), tri, np.arange(n))
+    assert (h["root"] < 0) == (n <= 4)
+
+
+def test_coincident_triangles_and_flat_extents(ctx):
+    rng = np.random.default_rng(3)
+    one = rng.random((1, 9), dtype=np.float32)
+    same = np.repeat(one, 300, axis=0)                                  # every Morton key equal: ties go by position
+    check_flat_layout(build_from_triangles(ctx, same), same, np.arange(300))
+    plane = rng.random((500, 3, 3), dtype=np.float32)
+    plane[:, :, 1] = 2.5                                                # zero extent on one axis
+    check_flat_layout(build_from_triangles(ctx, plane.reshape(-1, 9)), plane.reshape(-1, 9), np.arange(500))
+    far = rng.random((400, 9), dtype=np.float32) * np.float32(1e-3) + np.float32(1e6)    # tiny extent far from the origin
+    check_flat_layout(build_from_triangles(ctx, far), far, np.arange(400))
+
+
+@pytest.mark.parametrize("kind,target,wide", [("atrium", 6000, False), ("street_exterior", 150000, False), ("atrium", 5000, True)])
+def test_scene_build_and_frames_match_the_oracle(ctx, kind, target, wide):
+    from path_tracer_amd import hip
+    b = make_bundle(kind, target, 96, 56, max_bounce=4)
+    if wide:
+        b = dict(scenes.widen_indices(b), nodes=b["nodes"], flat=b["flat"], meta=b["meta"], width=b["width"], height=b["height"], ranks=b["ranks"])
+    n = b["triangles"].shape[0]
+    gs = hip.GpuScene(ctx, b, b["nodes"], None, b["meta"])
+    gs.wire(ctx.create_compute_renderpass())                            # sets the context's index layout for this scene
+    flat_buffer = ctx.build_flat(gs.indices_buffer, gs.positions_buffer, n)
+    blob = flat_buffer.read(np.uint8)
+    h = check_flat_layout(blob, b["triangles"], np.arange(n))
+    assert h["node_count"] < n / 2
+    ctx.bind_flat(gs.bvh_buffer, flat_buffer)
+    img, _, cap, st = gpu_frames(ctx, b, 2, "compute", gpu_scene=gs, capture=True, stats=True)
+    ref, counters, aov = oracle_frames(dict(b, flat=blob), 2, use_flat=True, materials=gs.materials_host, textures=gs.texture_table, aov=True)
+    assert np.array_equal(img, ref)
+    assert np.array_equal(cap[0], aov[0]) and np.array_equal(cap[1], aov[1])
+    assert {k: st[k] for k in ("rays", "nodes", "triangles")} == {k: counters[k] for k in ("rays", "nodes", "triangles")}
+    # against the host-built tree: the same closest hits (equal-t ties aside: the two trees break them differently)
+    host_img, _, _ = oracle_frames(b, 2, use_flat=True, materials=gs.materials_host, textures=gs.texture_table)
+    differing = int((np.abs(host_img - img).max(axis=2) > 0).sum())
+    assert differing <= max(2, img.shape[0] * img.shape[1] // 2000), differing
+
+
+def test_build_errors(ctx):
+    from path_tracer_amd import hip
+    idx = ctx.create_buffer(36)
+    pos = ctx.create_buffer(108)
+    with pytest.raises(hip.HipError):
+        ctx.build_flat(idx, pos, 0)
+    with pytest.raises(hip.HipError):
+        ctx.build_flat(idx, pos, 4)          # the index buffer holds 3 triangles
+    idx.destroy(); pos.destroy()
