@@ -132,6 +132,7 @@ def main():
     ap.add_argument("--instances", default="1x1", help="NXxNZ translated copies of the scene on a grid (e.g. 6x6 of the default scene = 10^8 triangles)")
     ap.add_argument("--pipeline", default="compute", choices=["compute", "compute.megakernel", "compute.wavefront"])
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline leg (0 = skip)")
+    ap.add_argument("--bvh", default="host", choices=["host", "gpu"], help="host: binned-SAH flattener (default); gpu: ptr_bvh_build_flat")
     ap.add_argument("--stream", default="torch", choices=["torch", "own"], help="the context's stream: torch's current stream or its own")
     ap.add_argument("--frames-in-flight", type=int, default=2, help="consecutive frames overlapped on internal streams (1 = none)")
     args = ap.parse_args()
@@ -168,6 +169,17 @@ def main():
     with torch.cuda.stream(stream):
         ctx = hip.Context(local_rank, stream=stream.cuda_stream if args.stream == "torch" else None)
         gpu = hip.GpuScene(ctx, sc, nodes, flat, meta)
+        if args.bvh == "gpu":
+            gpu.wire(ctx.create_compute_renderpass())          # the context's index layout for this scene
+            ctx.profile_enable(True)
+            t_build = time.perf_counter()
+            gpu_flat = ctx.build_flat(gpu.indices_buffer, gpu.positions_buffer, sc["triangles"].shape[0])
+            build_times["gpu_build_wall_s"] = time.perf_counter() - t_build
+            ctx.profile_enable(False)
+            build_times["gpu_build_device_ms"] = ctx.profile_read(reset=True).get("bvh.build_flat", dict(total_ms=0.0))["total_ms"]
+            ctx.bind_flat(gpu.bvh_buffer, gpu_flat)
+            flat = gpu_flat.read(np.uint8) if args.cpu_seconds > 0 else flat
+            log(rank, f"GPU BVH build: {build_times['gpu_build_device_ms']:.1f} ms on the device, {build_times['gpu_build_wall_s'] * 1e3:.1f} ms wall")
         W, H = args.width, args.height
         img_a = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
         img_b = torch.zeros_like(img_a)
@@ -275,7 +287,7 @@ def main():
                 "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                 "config": {"workload": line_workload,
                            "pipeline": "wavefront over flattened BVH" if wavefront else "megakernel over threaded BVH",
-                           "partition": "samples" if world > 1 else "none", "frames_in_flight": args.frames_in_flight,
+                           "partition": "samples" if world > 1 else "none", "frames_in_flight": args.frames_in_flight, "bvh_builder": args.bvh,
                            "rays_per_step_per_gpu": stats["rays"] / args.steps},
                 "ms_per_frame": elapsed / args.steps * 1e3,
                 "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -289,7 +301,7 @@ def main():
                              "solo": {"avg_launch_ms": ks["total_ms"] / max(1, ks["launches"]),
                                       "achieved": solo_bytes / (ks["total_ms"] * 1e-3) / 1e9 if ks["total_ms"] > 0 else 0.0,
                                       "frac": (solo_bytes / (ks["total_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS) if ks["total_ms"] > 0 else 0.0}},
-                "kernels_ms_per_step_solo": {n: v["total_ms"] / solo_frames for n, v in sorted(solo.items())},
+                "kernels_ms_per_step_solo": {n: v["total_ms"] / solo_frames for n, v in sorted(solo.items()) if v["launches"]},
                 "setup": build_times,
             }
             if world == 1 and args.cpu_seconds > 0:

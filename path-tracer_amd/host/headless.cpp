@@ -2,7 +2,7 @@
 // Builds the scene, wires the compute render pass exactly as src/main.cpp:261-270 does, renders `spp`
 // frames with the per-frame protocol of src/main.cpp:406-416 and writes the accumulated image.
 //
-//   ptr_headless --scene file.{ptrscene,gltf,glb} [--apply-transforms] --width W --height H --spp N [--max-bounce B] [--min-bounce B]
+//   ptr_headless --scene file.{ptrscene,gltf,glb} [--apply-transforms] [--gpu-bvh] --width W --height H --spp N [--max-bounce B] [--min-bounce B]
 //                [--dof 0|1] [--downscale D] [--debug-bvh 0|1] [--pipeline compute|compute.megakernel|compute.wavefront]
 //                [--pos x y z] [--target x y z] [--fov deg] [--aperture a] [--focus f] [--out image.pfm|image.ppm]
 #include <chrono>
@@ -47,7 +47,7 @@ scene_source load_source(const std::string& path, bool apply_transforms) {
 
 int main(int argc, char** argv) {
     std::string scene_path, out_path, pipeline = "compute";
-    bool apply_transforms = false;
+    bool apply_transforms = false, gpu_bvh = false;
     uint32_t width = 400, height = 225, spp = 1, max_bounce = 3, min_bounce = 1, dof = 0, debug_bvh = 0;
     int32_t downscale = 1;
     float pos[3] = { 13.f, 2.f, -3.f }, target[3] = { 0.f, 0.f, 0.f }, v_fov = 90.f, aperture = 0.1f, focus = 10.f;  // src/main.cpp:219-223
@@ -56,6 +56,7 @@ int main(int argc, char** argv) {
         auto next = [&]() -> const char* { if (i + 1 >= argc) { std::fprintf(stderr, "%s needs a value\n", argv[i]); std::exit(2); } return argv[++i]; };
         if (is("--scene")) scene_path = next();
         else if (is("--apply-transforms")) apply_transforms = true;
+        else if (is("--gpu-bvh")) gpu_bvh = true;
         else if (is("--out")) out_path = next();
         else if (is("--pipeline")) pipeline = next();
         else if (is("--width")) width = (uint32_t)std::atoi(next());
@@ -80,7 +81,7 @@ int main(int argc, char** argv) {
         const float aspect_ratio = (float)width / (float)height;
         const auto t_build = std::chrono::steady_clock::now();
         scene main_scene(camera(point3{ pos[0], pos[1], pos[2] }, point3{ target[0], target[1], target[2] }, v_fov, aspect_ratio, aperture, focus), width, height,
-                         load_source(scene_path, apply_transforms), pipeline != "compute.megakernel");
+                         load_source(scene_path, apply_transforms), pipeline != "compute.megakernel", gpu_bvh);
         main_scene.meta.max_bounce = max_bounce; main_scene.meta.min_bounce = min_bounce;
         main_scene.meta.enable_dof = dof; main_scene.meta.debug_bvh = debug_bvh; main_scene.meta.downscale_factor = downscale;
         const double build_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_build).count();

@@ -24,6 +24,7 @@ public:
 class Buffer {
 public:
     explicit Buffer(size_t size);
+    Buffer(ptr_handle adopted, size_t size) : device_buffer(adopted), buffer_size(size) {}  // a buffer the library created
     ~Buffer();
     void write(const void* data, off_t alloc_offset, size_t data_size) const;
     void read(void* dst, off_t offset, size_t size) const;

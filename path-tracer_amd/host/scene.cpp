@@ -9,7 +9,7 @@
 
 scene::metadata::metadata(const camera& cam_, uint32_t width_, uint32_t height_) : cam(cam_), width(width_), height(height_) {}
 
-scene::scene(const camera& cam, uint32_t width, uint32_t height, const scene_source& src, bool flatten_bvh) : meta(cam, width, height) {
+scene::scene(const camera& cam, uint32_t width, uint32_t height, const scene_source& src, bool flatten_bvh, bool gpu_bvh) : meta(cam, width, height) {
     const uint32_t iw = src.index_words;
     if (iw != 3 && iw != 4) throw std::runtime_error("scene: index_words must be 3 or 4");
     if (src.indices.empty() || src.indices.size() % iw) throw std::runtime_error("scene: the index array must hold whole triangles");
@@ -89,7 +89,14 @@ scene::scene(const camera& cam, uint32_t width, uint32_t height, const scene_sou
     bvh_buffer = upload(packed_nodes.data(), packed_nodes.size() * sizeof(packed_bvh_node));
     materials_buffer = upload(materials.data(), materials.size() * sizeof(gpu_material));
 
-    if (flatten_bvh) {
+    if (flatten_bvh && gpu_bvh) {
+        ptr_handle built = 0;
+        hiprenderer::check(ptr_bvh_build_flat(hiprenderer::api, indices_buffer->device_buffer, positions_buffer->device_buffer, (uint32_t)triangle_count, &built),
+                           "ptr_bvh_build_flat");
+        flat_bvh_buffer = new Buffer(built, 64 + 128 * triangle_count);
+        hiprenderer::check(ptr_bvh_bind_flat(hiprenderer::api, bvh_buffer->device_buffer, flat_bvh_buffer->device_buffer), "ptr_bvh_bind_flat");
+        bvh_mode += " + gpu radix tree";
+    } else if (flatten_bvh) {
         const std::vector<uint8_t> flat = bvh::flatten(triangles, ranks);
         flat_bvh_buffer = upload(flat.data(), flat.size());
         hiprenderer::check(ptr_bvh_bind_flat(hiprenderer::api, bvh_buffer->device_buffer, flat_bvh_buffer->device_buffer), "ptr_bvh_bind_flat");

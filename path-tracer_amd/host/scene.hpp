@@ -38,7 +38,9 @@ public:
     };
     static_assert(sizeof(camera) == 128, "camera block");
 
-    scene(const camera& cam, uint32_t width, uint32_t height, const scene_source& source, bool flatten_bvh = true);
+    // flatten_bvh: also build the flattened layout the wavefront pipeline traverses -- on the host (binned SAH, the better
+    // tree) or, with gpu_bvh, on the GPU from the uploaded buffers (ptr_bvh_build_flat: milliseconds instead of seconds).
+    scene(const camera& cam, uint32_t width, uint32_t height, const scene_source& source, bool flatten_bvh = true, bool gpu_bvh = false);
     ~scene();
 
     // Writes `meta` where the kernels read it (slot 0 of the scene buffer).

@@ -81,6 +81,26 @@ def test_headless_driver_wide_index_scene(tmp_path):
     assert np.array_equal(read_ptrf(out_file), ref)
 
 
+def test_headless_driver_gpu_built_bvh(tmp_path):
+    """--gpu-bvh: the flattened tree comes from ptr_bvh_build_flat; same closest hits as the reference-order walk except ties."""
+    W, H, SPP = 72, 40, 2
+    b = make_bundle("atrium", 3000, W, H, max_bounce=4)
+    scene_file = str(tmp_path / "scene.ptrscene")
+    scenes.save_ptrscene(b, scene_file)
+    c = b["camera"]
+    images = {}
+    for name, extra in (("gpu", ["--gpu-bvh"]), ("mega", ["--pipeline", "compute.megakernel"])):
+        out_file = str(tmp_path / f"{name}.pfm")
+        cmd = [HEADLESS, "--scene", scene_file, "--width", str(W), "--height", str(H), "--spp", str(SPP), "--max-bounce", "4", *extra,
+               "--out", out_file, "--pos", *map(str, c["pos"]), "--target", *map(str, c["target"]),
+               "--fov", str(c["v_fov"]), "--aperture", str(c["aperture"]), "--focus", str(c["focus"])]
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0, r.stderr
+        images[name] = read_ptrf(out_file)
+    differing = int((np.abs(images["gpu"] - images["mega"]).max(axis=2) > 0).sum())
+    assert differing <= 3, differing
+
+
 def test_headless_reports_errors():
     r = subprocess.run([HEADLESS, "--scene", "/nonexistent.ptrscene"], capture_output=True, text=True, timeout=60)
     assert r.returncode == 1 and "cannot open" in r.stderr
