@@ -43,7 +43,7 @@ def build_scene(args, rank):
         t1 = time.time()
         nodes = np.zeros((1, 8), np.uint32)
         nodes[0, 3] = 0xFFFFFFFF
-        flat = host.bvh_flatten(sc["triangles"], None, threads=min(16, os.cpu_count() or 1))
+        flat = None if getattr(args, "bvh", "host") == "gpu" else host.bvh_flatten(sc["triangles"], None, threads=min(16, os.cpu_count() or 1))
         t3 = time.time()
         c = sc["camera"]
         cam = host.camera(c["pos"], c["target"], c["v_fov"], args.width / args.height, c["aperture"], c["focus"])

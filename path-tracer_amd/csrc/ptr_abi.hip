@@ -230,9 +230,14 @@ int ensure_slot(ptr_ctx* c, ptr_ctx::FrameSlot& slot) {
 }
 
 // ---- wavefront scratch (one per frame slot) ----
-int ensure_scratch(ptr_ctx* c, ptr_ctx::FrameSlot& slot, uint32_t capacity) {
-    if (slot.scratch.capacity >= capacity && slot.scratch_block &&
+int ensure_scratch(ptr_ctx* c, ptr_ctx::FrameSlot& slot, uint32_t capacity, uint32_t stack_need) {
+    // spill entries per lane: what the tree can need beyond the LDS part, plus the three pushes of the step in progress
+    uint32_t spill = stack_need + 3u > ptr::kStackLds ? stack_need + 3u - ptr::kStackLds : 0u;
+    spill = spill < ptr::kStackSpill ? ptr::kStackSpill : ((spill + 15u) & ~15u);
+    if (slot.scratch.capacity >= capacity && slot.scratch_block && slot.scratch.spill_entries >= spill &&
         slot.scratch.extend_blocks == (uint32_t)c->cu_count * (uint32_t)c->opt_extend_blocks_per_cu) return PTR_OK;
+    if (slot.scratch.capacity > capacity) capacity = slot.scratch.capacity;          // never shrink what another scene still needs
+    if (slot.scratch.spill_entries > spill) spill = slot.scratch.spill_entries;
     if (slot.scratch_block) {
         int rc = drain_frames(c); if (rc) return rc;
         PTR_HIP_CHECK(c, hipStreamSynchronize(c->stream));
@@ -241,7 +246,7 @@ int ensure_scratch(ptr_ctx* c, ptr_ctx::FrameSlot& slot, uint32_t capacity) {
     }
     const size_t cap = ((size_t)capacity + 255) & ~(size_t)255;
     const uint32_t extend_blocks = (uint32_t)c->cu_count * (uint32_t)c->opt_extend_blocks_per_cu;
-    const size_t spill_words = (size_t)extend_blocks * (ptr::kExtendThreads / 64) * ptr::kStackSpill * 64;
+    const size_t spill_words = (size_t)extend_blocks * (ptr::kExtendThreads / 64) * spill * 64;
     // 2 generations x 3 records of 4 words, hits + samples (4 words each), counters, spill
     const size_t words = cap * (2 * 12 + 8) + 64 + spill_words;
     PTR_HIP_CHECK(c, hipMalloc(&slot.scratch_block, words * 4));
@@ -259,6 +264,7 @@ int ensure_scratch(ptr_ctx* c, ptr_ctx::FrameSlot& slot, uint32_t capacity) {
     s.stack_spill = (int32_t*)take(spill_words);
     s.capacity = (uint32_t)cap;
     s.extend_blocks = extend_blocks;
+    s.spill_entries = spill;
     return PTR_OK;
 }
 
@@ -408,7 +414,7 @@ int dispatch_compute(ptr_ctx* c, const uint8_t constants[64], uint32_t gx, uint3
         if ((hd.nodes_offset & 63u) || (hd.triangles_offset & 63u)) return fail(c, PTR_E_STATE, "flattened layout: sections are not 64-byte aligned");
         if (hd.nodes_offset + (uint64_t)hd.node_count * 64 > flat_buf->size || hd.triangles_offset + (uint64_t)hd.triangle_count * 64 > flat_buf->size)
             return fail(c, PTR_E_STATE, "flattened layout: sections exceed the buffer");
-        if (hd.max_depth > ptr::kStackLds + ptr::kStackSpill - 2) return fail(c, PTR_E_STATE, "flattened layout: deeper than the traversal stack");
+        if (hd.max_depth > ptr::kStackMax) return fail(c, PTR_E_STATE, "flattened layout: needs a traversal stack of %u entries, %u at most", hd.max_depth, ptr::kStackMax);
         if (hd.root >= 0 ? (uint32_t)hd.root >= hd.node_count : ((uint32_t)~hd.root >> 2) + ((uint32_t)~hd.root & 3u) + 1u > hd.triangle_count)
             return fail(c, PTR_E_STATE, "flattened layout: root reference out of range");
         flat_buf->flat_view.nodes = (const float4*)((const uint8_t*)flat_buf->ptr + hd.nodes_offset);
@@ -435,7 +441,7 @@ int dispatch_compute(ptr_ctx* c, const uint8_t constants[64], uint32_t gx, uint3
 
     // queue slots: whole 8x8 tiles of the owned rows (padded by one stripe); samples are indexed by pixel
     const uint32_t padded = ((meta.width + 7u) / 8u) * ((meta.height + 7u) / 8u + c->part_stripe / 8u) * 64u;
-    if ((rc = ensure_scratch(c, slot, padded > meta.width * meta.height ? padded : meta.width * meta.height))) return rc;
+    if ((rc = ensure_scratch(c, slot, padded > meta.width * meta.height ? padded : meta.width * meta.height, fv.max_depth))) return rc;
     const ptr::WavefrontScratch& w = slot.scratch;
 
     if (overlap) {

@@ -30,12 +30,14 @@ struct WavefrontScratch {
     int32_t* stack_spill;   // traversal stack overflow area of the persistent extend grid
     uint32_t capacity;
     uint32_t extend_blocks; // persistent grid size
+    uint32_t spill_entries; // per-lane entries of stack_spill (sized for the deepest tree bound so far)
 };
 
 constexpr uint32_t kMaxBounceSlots = 16;   // counters per array; deeper paths reuse the slots cyclically
 constexpr uint32_t kExtendThreads = 256;
 constexpr uint32_t kStackLds = 16;         // per-lane traversal stack entries kept in LDS
-constexpr uint32_t kStackSpill = 48;       // further entries in global memory (64 total >= FLAT_BVH_MAX_DEPTH)
+constexpr uint32_t kStackSpill = 48;       // least number of further entries in global memory; grows with the bound tree's stack need
+constexpr uint32_t kStackMax = 254;        // deepest stack a flattened layout may ask for (the oracle's restatement holds 256)
 
 // compute.comp as one kernel over the threaded node array (one wave = one 8x8 workgroup).
 hipError_t launch_megakernel(hipStream_t s, const SceneView& sv, uint32_t groups_x, uint32_t groups_y, bool stats);

@@ -392,7 +392,7 @@ hipError_t build_flat_bvh(hipStream_t s, const SceneView& sv, uint32_t n, uint32
         hd.root = 0;
         hd.node_count = host_scene[8 + 0];
         hd.max_depth = host_scene[8 + 2];
-        if (hd.max_depth > kStackLds + kStackSpill - 2u) { *status = -5; cleanup(); return hipSuccess; }
+        if (hd.max_depth > kStackMax) { *status = -5; cleanup(); return hipSuccess; }
     }
     // scene box: decode the ordered integers on the host
     for (int a = 0; a < 6; a++) {

@@ -134,7 +134,7 @@ __global__ __launch_bounds__(kExtendThreads, 4) void ptr_wf_extend(FlatView fv, 
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave_in_block = threadIdx.x >> 6;
     int32_t* my_lds = lds_stack + wave_in_block * kStackLds * 64 + lane;
-    int32_t* my_spill = w.stack_spill + (size_t)(blockIdx.x * (kExtendThreads / 64) + wave_in_block) * kStackSpill * 64 + lane;
+    int32_t* my_spill = w.stack_spill + (size_t)(blockIdx.x * (kExtendThreads / 64) + wave_in_block) * w.spill_entries * 64 + lane;
 
     const uint32_t count = w.counters[slot_b];
     const uint32_t global_wave = blockIdx.x * (kExtendThreads / 64) + wave_in_block;

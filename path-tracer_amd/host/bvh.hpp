@@ -73,7 +73,7 @@ static_assert(sizeof(flat_bvh_header) == 64, "header is one 64-byte line");
 
 constexpr uint32_t FLAT_BVH_MAGIC = 0x46525450u;  // "PTRF"
 constexpr uint32_t FLAT_BVH_VERSION = 2;          // 4-wide nodes with quantised child boxes
-constexpr uint32_t FLAT_BVH_MAX_DEPTH = 62;       // traversal stack capacity in the kernels
+constexpr uint32_t FLAT_BVH_MAX_DEPTH = 254;      // most stack entries a layout may ask for (the kernels size their spill area from the header)
 constexpr int32_t FLAT_BVH_EMPTY_CHILD = INT32_MIN;
 
 class bvh_build_error : public std::runtime_error {

@@ -147,7 +147,7 @@ def check_flat_layout(flat, triangles, ranks, tight=True):
     import sys
     sys.setrecursionlimit(10000)
     lo, hi = bounds_of(h["root"], 0)
-    assert seen.all() and worst_stack <= h["max_depth"] <= 62
+    assert seen.all() and worst_stack <= h["max_depth"] <= 254
     assert np.array_equal(lo, h["scene_min"]) and np.array_equal(hi, h["scene_max"])
     return h
 
