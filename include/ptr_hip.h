@@ -129,6 +129,10 @@ int ptr_set_sample_partition(ptr_ctx* ctx, uint32_t rank, uint32_t world);
  *                              vertex id | one byte of the 24-bit material id (src/scene.cpp:140-142, ray.h:20-30);
  *                              4: extension for scenes with more than 2^24 vertices (no counterpart in the reference):
  *                              four plain words per triangle, v0, v1, v2, material id; the buffer must be 16-byte aligned.
+ *      "scene.validate"        1 (default): before a "compute" dispatch first uses a set of scene buffers (and again after any
+ *                              ptr_buffer_write to them) the library checks on the GPU that every vertex id, material id,
+ *                              node link and child reference stays inside the buffer it indexes, and fails the dispatch with
+ *                              PTR_E_RANGE otherwise (one synchronisation per upload); 0: trust the caller.
  *      "shade.pregather"       1 (default): the wavefront shade step reads one 80-byte record per hit triangle (vertex
  *                              normals, uvs, material id, geometry normal) that the library gathers once from the index /
  *                              positions / normals / uvs buffers of the dispatch and re-gathers after any ptr_buffer_write

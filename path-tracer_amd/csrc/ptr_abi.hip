@@ -26,6 +26,7 @@ struct BufferRec {
     bool flat_view_valid = false;  // this buffer holds a flattened layout whose header was parsed
     uint64_t generation = 0;       // context-wide write counter at this buffer's creation / last write
     ptr::FlatView flat_view{};
+    uint32_t flat_nodes = 0, flat_triangles = 0;  // counts from the parsed header
 };
 struct ImageRec {
     void* ptr = nullptr;
@@ -100,6 +101,13 @@ struct ptr_ctx {
     uint64_t shade_key[8] = {};
     bool shade_key_valid = false;
     uint64_t write_epoch = 0;       // bumped by every buffer creation and write
+    // verdicts of the scene-contents check, by what was checked (addresses + write generations); a few entries so that
+    // dispatches alternating between scenes or pipelines do not re-check (and synchronise) every time
+    struct Validated { uint64_t key[16]; bool used = false; };
+    Validated validated[4];
+    int validated_next = 0;
+    int opt_validate = 1;
+    uint32_t* d_validate = nullptr;
     uint64_t shared_epoch = 0;      // write_epoch of the last change to what every frame reads: textures, image table, shading records
     // small host->device writes (the per-frame 160-byte metadata) go through a ring of pinned slots so that
     // Buffer::write returns without draining the stream
@@ -350,6 +358,44 @@ int ensure_shade_records(ptr_ctx* c, const uint64_t addr[7], const ptr_handle ha
     return PTR_OK;
 }
 
+// The index words and the tree layouts hold indices into other buffers: checked on the GPU once per upload, so that a
+// bad scene fails the dispatch instead of faulting the device.
+int validate_scene(ptr_ctx* c, const uint64_t addr[7], const ptr_handle handles[7], const ptr::SceneView& sv, BufferRec* flat_buf, bool wavefront) {
+    if (!c->opt_validate) return PTR_OK;
+    uint64_t key[16] = {};
+    for (int i = 1; i < 7; i++) { key[i - 1] = addr[i]; key[5 + i] = c->buffers[handles[i]].generation; }
+    key[12] = flat_buf ? flat_buf->generation : 0;
+    key[13] = (uint64_t)c->opt_index_words | (wavefront ? 16u : 0u);
+    for (const auto& v : c->validated) if (v.used && !memcmp(v.key, key, sizeof key)) return PTR_OK;
+
+    auto bytes_from = [&](int i) { const BufferRec& b = c->buffers[handles[i]]; return (uint64_t)(uintptr_t)b.ptr + b.size - addr[i]; };
+    const uint64_t triangles = bytes_from(2) / (4u * (uint64_t)c->opt_index_words);
+    uint64_t vertices = bytes_from(3) / 12u;
+    if (bytes_from(4) / 12u < vertices) vertices = bytes_from(4) / 12u;
+    if (bytes_from(5) / 8u < vertices) vertices = bytes_from(5) / 8u;
+    const uint64_t materials = bytes_from(6) / sizeof(ptr::Material);
+    // the reference's builder emits 2N-1 nodes for N triangles (src/bvh.cpp:48-86); a larger buffer's tail is not part of the tree
+    uint64_t threaded = wavefront ? 0u : bytes_from(1) / sizeof(ptr::ThreadedNode);
+    if (triangles && threaded > 2 * triangles - 1) threaded = 2 * triangles - 1;
+    if (triangles > 0xffffffffull || threaded > 0xffffffffull) return fail(c, PTR_E_RANGE, "scene: buffers larger than 2^32 records");
+    if (!c->d_validate) PTR_HIP_CHECK(c, hipMalloc((void**)&c->d_validate, 16));
+    const ptr::FlatView* fv = wavefront && flat_buf ? &flat_buf->flat_view : nullptr;
+    PTR_HIP_CHECK(c, ptr::launch_validate_scene(c->stream, sv, (uint32_t)triangles, (uint32_t)threaded, fv, fv ? flat_buf->flat_nodes : 0u,
+                                                fv ? flat_buf->flat_triangles : 0u, c->d_validate));
+    uint32_t out[4];
+    PTR_HIP_CHECK(c, hipMemcpyAsync(out, c->d_validate, sizeof out, hipMemcpyDeviceToHost, c->stream));
+    PTR_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+    if (triangles && out[0] >= vertices) return fail(c, PTR_E_RANGE, "scene: the index buffer names vertex %u, the vertex buffers hold %llu", out[0], (unsigned long long)vertices);
+    if (triangles && out[1] >= materials) return fail(c, PTR_E_RANGE, "scene: the index buffer names material %u, the material buffer holds %llu", out[1], (unsigned long long)materials);
+    if (out[2]) return fail(c, PTR_E_RANGE, "scene: %u links or primitive ids of the bvh nodes point outside the node / index buffers", out[2]);
+    if (out[3]) return fail(c, PTR_E_RANGE, "scene: %u child references or primitive ids of the flattened layout point outside it", out[3]);
+    ptr_ctx::Validated& slot = c->validated[c->validated_next];
+    c->validated_next = (c->validated_next + 1) % 4;
+    memcpy(slot.key, key, sizeof key);
+    slot.used = true;
+    return PTR_OK;
+}
+
 int dispatch_compute(ptr_ctx* c, const uint8_t constants[64], uint32_t gx, uint32_t gy, int force /*0 auto,1 mega,2 wavefront*/) {
     const ParsedConstants k = parse_constants(constants);
     ptr::SceneMeta meta;
@@ -397,8 +443,9 @@ int dispatch_compute(ptr_ctx* c, const uint8_t constants[64], uint32_t gx, uint3
     if (c->stats_on) c->stats_frames++;
 
     if (!wavefront) {
-        // the threaded walk starts at node 0 and trusts the links: at least one node must be there
+        // the threaded walk starts at node 0: at least one node must be there
         if (k.addr[1] + 32 > (uint64_t)(uintptr_t)bvh_buf->ptr + bvh_buf->size) return fail(c, PTR_E_STATE, "bvh buffer holds no node");
+        if ((rc = validate_scene(c, k.addr, handles, sv, nullptr, false))) return rc;
         ScopedProfile prof(c, "compute.megakernel");
         PTR_HIP_CHECK(c, ptr::launch_megakernel(c->stream, sv, gx, gy, c->stats_on));
         return PTR_OK;
@@ -421,9 +468,12 @@ int dispatch_compute(ptr_ctx* c, const uint8_t constants[64], uint32_t gx, uint3
         flat_buf->flat_view.triangles = (const float4*)((const uint8_t*)flat_buf->ptr + hd.triangles_offset);
         flat_buf->flat_view.root = hd.root;
         flat_buf->flat_view.max_depth = hd.max_depth;
+        flat_buf->flat_nodes = hd.node_count;
+        flat_buf->flat_triangles = hd.triangle_count;
         flat_buf->flat_view_valid = true;
     }
     const ptr::FlatView fv = flat_buf->flat_view;
+    if ((rc = validate_scene(c, k.addr, handles, sv, flat_buf, true))) return rc;
     if ((rc = ensure_shade_records(c, k.addr, handles, &sv))) return rc;
 
     const uint32_t domain_w = gx * 8u < meta.width ? gx * 8u : meta.width;
@@ -534,6 +584,7 @@ int ptr_ctx_destroy(ptr_ctx* c) {
     for (auto& b : c->buffers) if (b.alive && b.ptr) (void)hipFree(b.ptr);
     for (auto& im : c->images) if (im.alive && im.owned && im.ptr) (void)hipFree(im.ptr);
     if (c->shade_records) (void)hipFree(c->shade_records);
+    if (c->d_validate) (void)hipFree(c->d_validate);
     if (c->d_images) (void)hipFree(c->d_images);
     if (c->d_stats) (void)hipFree(c->d_stats);
     for (auto e : c->stage_done) if (e) (void)hipEventDestroy(e);
@@ -916,6 +967,11 @@ int ptr_set_option(ptr_ctx* c, const char* key, int value) {
     if (!strcmp(key, "scene.index_words")) {
         if (value != 3 && value != 4) return fail(c, PTR_E_INVALID, "scene.index_words: 3 or 4");
         c->opt_index_words = value;
+        return PTR_OK;
+    }
+    if (!strcmp(key, "scene.validate")) {
+        if (value != 0 && value != 1) return fail(c, PTR_E_INVALID, "scene.validate: 0 or 1");
+        c->opt_validate = value;
         return PTR_OK;
     }
     if (!strcmp(key, "shade.pregather")) {

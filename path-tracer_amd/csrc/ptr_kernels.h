@@ -66,6 +66,11 @@ hipError_t launch_wf_accumulate(hipStream_t s, const SceneView& sv, const Wavefr
 size_t flat_build_blob_bytes(uint32_t triangle_count);
 hipError_t build_flat_bvh(hipStream_t s, const SceneView& sv, uint32_t triangle_count, uint32_t vertex_count, void* blob, size_t blob_bytes, int* status);
 
+// Contents check of the buffers a "compute" dispatch dereferences (ptr_kernels_validate.hip).  out4 (device, 4 words):
+// max vertex id, max material id, violations in the threaded nodes, violations in the flattened layout.
+hipError_t launch_validate_scene(hipStream_t s, const SceneView& sv, uint32_t triangle_count, uint32_t threaded_nodes, const FlatView* fv,
+                                 uint32_t flat_nodes, uint32_t flat_triangles, uint32_t* out4);
+
 // Per-function test kernel (ptr_kernels_unit.hip): index of `name` (< 0 if unknown) with its record sizes in 32-bit words.
 int unit_function_lookup(const char* name, uint32_t* in_words, uint32_t* out_words);
 hipError_t launch_unit_function(hipStream_t s, int fn, const uint32_t* in, uint32_t in_words, uint32_t* out, uint32_t out_words, uint32_t count);

@@ -188,6 +188,46 @@ def test_frames_in_flight_survive_stream_changes_and_teardown():
         runtime.hipStreamDestroy(side)
 
 
+def test_bad_scene_contents_fail_the_dispatch_instead_of_faulting(ctx):
+    """Vertex ids, material ids, node links and child references are indices into other buffers: an out-of-range one is
+    reported by ptr_dispatch (checked on the GPU once per upload), and the scene works again once it is repaired."""
+    from path_tracer_amd import hip
+    b = make_bundle("atrium", 3000, 48, 32, max_bounce=3)
+    good, gs, _, _ = gpu_frames(ctx, b, 1, "compute.wavefront")
+    n_vertices = len(b["positions"]) // 3
+    idx = np.asarray(b["indices"], np.uint32).copy()
+
+    def expect_failure(pipeline, what):
+        with pytest.raises(hip.HipError, match=what):
+            gpu_frames(ctx, b, 1, pipeline, gpu_scene=gs)
+
+    bad = idx.copy(); bad[7] = (bad[7] & np.uint32(0xFF000000)) | np.uint32(n_vertices)           # one vertex id past the end
+    gs.indices_buffer.write(bad)
+    expect_failure("compute.wavefront", "vertex")
+    expect_failure("compute.megakernel", "vertex")
+    bad = idx.copy(); bad[2::3] |= np.uint32(0xFF000000)                                             # material 255 and up
+    gs.indices_buffer.write(bad)
+    expect_failure("compute.wavefront", "material")
+    gs.indices_buffer.write(idx)
+
+    nodes = np.asarray(b["nodes"], np.uint32).copy()
+    bad = nodes.copy(); bad[5, 3] = np.uint32(len(nodes) + 10)                                      # a skip link past the end
+    gs.bvh_buffer.write(bad)
+    expect_failure("compute.megakernel", "bvh nodes")
+    gs.bvh_buffer.write(nodes)
+
+    flat = np.asarray(b["flat"], np.uint8).copy()
+    h = flat[:64].view(np.uint32)
+    bad = flat.copy()
+    bad[64 + 16:64 + 20].view(np.int32)[0] = int(h[2]) + 5                                          # root's first child: no such node
+    gs.flat_buffer.write(bad)
+    expect_failure("compute.wavefront", "flattened layout")
+    gs.flat_buffer.write(flat)
+
+    again, _, _, _ = gpu_frames(ctx, b, 1, "compute.wavefront", gpu_scene=gs)
+    assert_same(again, good, "after repairing the buffers")
+
+
 def test_auto_pipeline_picks_wavefront_when_a_flat_layout_is_bound(ctx):
     b = make_bundle("tiny", 0, 48, 32, max_bounce=3)
     img_auto, gs, _, _ = gpu_frames(ctx, b, 2, "compute")
