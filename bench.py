@@ -137,6 +137,13 @@ def main():
     ap.add_argument("--frames-in-flight", type=int, default=2, help="consecutive frames overlapped on internal streams (1 = none)")
     args = ap.parse_args()
 
+    # Rank 0 must print ONE line on stdout.  Libraries underneath write there too (RCCL prints a version banner when the
+    # first communicator is created): everything written to fd 1 from here on goes to stderr, the result line goes to the
+    # saved descriptor.
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
 
@@ -152,9 +159,13 @@ def main():
     if "PTR_BENCH_DEVICE" in os.environ:
         local_rank = int(os.environ["PTR_BENCH_DEVICE"])
     backend = os.environ.get("PTR_BENCH_BACKEND", "nccl")
+    # PTR_BENCH_FORCE_DIST=1: run the exchange path (process group, barriers, linearize / all-reduce / resolve) with ONE rank,
+    # to rehearse the RCCL leg on a one-GPU box
+    multi = world > 1 or bool(os.environ.get("PTR_BENCH_FORCE_DIST"))
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         else:
@@ -209,13 +220,13 @@ def main():
             return by_handle[latest.handle]
 
         def barrier():
-            if world > 1:
+            if multi:
                 dist.barrier()
             torch.cuda.synchronize()
 
         for _ in range(args.warmup):
             loop.frame()
-        if world > 1:
+        if multi:
             combine()
         barrier()
         loop.reset()
@@ -228,10 +239,10 @@ def main():
         t0 = time.perf_counter()
         for _ in range(args.steps):
             loop.frame()
-        if world > 1:
+        if multi:
             combine()
         torch.cuda.synchronize()
-        if world > 1:
+        if multi:
             dist.barrier()
         elapsed = time.perf_counter() - t0
         ctx.profile_enable(False)
@@ -263,7 +274,7 @@ def main():
         reduce_device = "cuda" if backend == "nccl" else "cpu"
         t = torch.tensor([elapsed], dtype=torch.float64, device=reduce_device)
         work = torch.tensor([stats["rays"], stats["nodes"], stats["triangles"], stats["shaded"]], dtype=torch.float64, device=reduce_device)
-        if world > 1:
+        if multi:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dist.all_reduce(work, op=dist.ReduceOp.SUM)
         elapsed = float(t.item())
@@ -308,9 +319,9 @@ def main():
                 line["cpu_baseline"] = cpu_baseline(args, sc, nodes, flat, meta, gpu, args.cpu_seconds)
             else:
                 line["cpu_baseline"] = None
-            print(json.dumps(line), flush=True)
+            os.write(result_fd, (json.dumps(line) + "\n").encode())
         ctx.close()
-    if world > 1:
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
 
