@@ -723,7 +723,8 @@ static void shade_pixel(const orc_frame* f, uint32_t gx, uint32_t gy, orc_counte
     const meta_t* m = (const meta_t*)f->scene_meta;
     if (gx >= m->width || gy >= m->height) return;
     int32_t cx = (int32_t)gx * m->downscale_factor, cy = (int32_t)gy * m->downscale_factor;
-    uint32_t seed = ((uint32_t)cx * 1973u + (uint32_t)cy * 9277u + m->sample_index * 26699u) | 1u;
+    const uint32_t seed_index = f->seed_sample_index ? f->seed_sample_index : m->sample_index;
+    uint32_t seed = ((uint32_t)cx * 1973u + (uint32_t)cy * 9277u + seed_index * 26699u) | 1u;
     ray_t r = generate_camera_ray(m, cx, cy, seed);
 
     int32_t* aov_prim = f->aov_prim ? f->aov_prim + 2 * ((size_t)gy * m->width + gx) : NULL;

@@ -74,6 +74,9 @@ typedef struct {
     uint32_t index_words;        /* 0 or 3: the reference's packing (3 words per triangle, 24-bit vertex id | one byte of
                                     the material id, src/scene.cpp:140-142); 4: extension for scenes past 2^24 vertices,
                                     4 plain words per triangle: v0, v1, v2, material */
+    uint32_t seed_sample_index;  /* 0: the per-pixel seed uses the metadata's sample_index (compute.comp:270); otherwise this value
+                                    seeds the pixel while the metadata's sample_index still weights the accumulation: the sample
+                                    partition over several GPUs, where a GPU's k-th frame draws global sample (k-1)*world+rank+1 */
 } orc_frame;
 
 /* compute.comp main() over the rows [y0, y1) of the dispatch, `threads` worker threads. */

@@ -32,7 +32,7 @@ class Frame(C.Structure):
                 ("positions", C.c_void_p), ("normals", C.c_void_p), ("uvs", C.c_void_p), ("materials", C.c_void_p),
                 ("textures", C.POINTER(Texture)), ("texture_count", C.c_uint32), ("accumulation", Image),
                 ("output", Image), ("aov_prim", C.c_void_p), ("aov_t", C.c_void_p), ("flat_bvh", C.c_void_p),
-                ("use_flat", C.c_int32), ("index_words", C.c_uint32)]
+                ("use_flat", C.c_int32), ("index_words", C.c_uint32), ("seed_sample_index", C.c_uint32)]
 
 
 def build(force=False):
@@ -100,6 +100,7 @@ class OracleScene:
         self.nodes = np.ascontiguousarray(arrays["nodes"])
         self.indices = np.ascontiguousarray(arrays["indices"], dtype=np.uint32)
         self.index_words = int(arrays.get("index_words", 3))
+        self.seed_sample_index = 0   # see orc_frame.seed_sample_index
         self.positions = f32(arrays["positions"])
         self.normals = f32(arrays["normals"])
         self.uvs = f32(arrays["uvs"])
@@ -128,6 +129,7 @@ class OracleScene:
         f.bvh_nodes = self.nodes.ctypes.data
         f.indices = self.indices.ctypes.data
         f.index_words = self.index_words
+        f.seed_sample_index = self.seed_sample_index
         f.positions = self.positions.ctypes.data
         f.normals = self.normals.ctypes.data
         f.uvs = self.uvs.ctypes.data

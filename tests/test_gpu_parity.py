@@ -228,6 +228,69 @@ def test_bad_scene_contents_fail_the_dispatch_instead_of_faulting(ctx):
     assert_same(again, good, "after repairing the buffers")
 
 
+def test_sample_partition_exchange(ctx):
+    """Two ranks (two partitions of one context here), each keeping the running mean of its own global samples:
+    every rank's frames equal the oracle seeded with that rank's sample numbers, and linearize -> sum -> resolve is
+    the per-pixel arithmetic it says it is."""
+    import ctypes as C
+    import pyoracle
+    from path_tracer_amd import hip
+    world, frames = 2, 3
+    b = make_bundle("atrium", 3000, 56, 40, max_bounce=4)
+    W, H = b["width"], b["height"]
+    gs = hip.GpuScene(ctx, b, b["nodes"], b["flat"], b["meta"])
+    L = pyoracle.lib()
+    linear = []
+    try:
+        for rank in range(world):
+            ctx.set_sample_partition(rank, world)
+            gs.set_meta(b["meta"])
+            loop = hip.FrameLoop(ctx, gs, W, H, "compute.wavefront")
+            for _ in range(frames):
+                loop.frame()
+            img = loop.latest().read()
+            o = pyoracle.OracleScene(dict(b, materials=gs.materials_host, textures=gs.texture_table))
+            acc = np.zeros((H, W, 4), np.float32)
+            out = np.zeros_like(acc)
+            for k in range(1, frames + 1):
+                o.set_meta(sample_index=k)
+                o.seed_sample_index = (k - 1) * world + rank + 1
+                o.render(acc, out, use_flat=True)
+                acc, out = out, acc
+            assert_same(img, acc, f"rank {rank} of {world}")
+            # linearize on the device: (srgb_to_linear(rgb), 1)
+            rp = ctx.create_compute_renderpass()
+            rp.set_pipeline("linearize")
+            rp.set_ouput_texture(loop.output)
+            rp.set_constant(60, loop.latest())
+            rp.set_dispatch_size(1, 1, 1)
+            rp.execute()
+            lin = loop.output.read()
+            want = np.ones_like(img)
+            for y in range(H):
+                for x in range(W):
+                    L.orc_srgb_to_linear(img[y, x, :3].ctypes.data_as(C.c_void_p), want[y, x, :3].ctypes.data_as(C.c_void_p))
+            assert_same(lin, want, "linearize")
+            linear.append(lin)
+        # what the all-reduce does, then resolve on the device: linear_to_srgb(rgb / w)
+        total = linear[0] + linear[1]
+        loop.output.update(total)
+        rp.set_pipeline("resolve")
+        rp.set_ouput_texture(loop.latest())
+        rp.set_constant(60, loop.output)
+        rp.execute()
+        final = loop.latest().read()
+        want = np.ones_like(final)
+        mean = (total[..., :3] / total[..., 3:4]).astype(np.float32)
+        for y in range(H):
+            for x in range(W):
+                L.orc_linear_to_srgb(mean[y, x].ctypes.data_as(C.c_void_p), want[y, x, :3].ctypes.data_as(C.c_void_p))
+        assert_same(final, want, "resolve")
+        assert (total[..., 3] == world).all()
+    finally:
+        ctx.set_sample_partition(0, 1)
+
+
 def test_auto_pipeline_picks_wavefront_when_a_flat_layout_is_bound(ctx):
     b = make_bundle("tiny", 0, 48, 32, max_bounce=3)
     img_auto, gs, _, _ = gpu_frames(ctx, b, 2, "compute")
