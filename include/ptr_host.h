@@ -60,6 +60,9 @@ void ptrh_scene_free(void* scene);
 /* PNG / JPEG file image -> RGBA8 (what stbi_load(path, &w, &h, &channels, 4) returns, src/gltf.cpp:103-112);
  * *rgba_out is malloc'ed, free with ptrh_free. */
 int32_t ptrh_image_decode(const uint8_t* bytes, uint64_t size, int32_t* width, int32_t* height, int32_t* channels, uint8_t** rgba_out);
+/* width*height RGB8 texels -> a PNG file image (malloc'ed, free with ptrh_free): the output stage's container next to the
+ * reference's PPM text (src/color.cpp:6-14 gives the 8-bit values). */
+int32_t ptrh_image_encode_png(const uint8_t* rgb, uint32_t width, uint32_t height, uint8_t** file_out, uint64_t* size_out);
 /* Parses a JSON text and re-serialises it compactly (malloc'ed, free with ptrh_free): the reader's test hook. */
 int32_t ptrh_json_dump(const char* text, uint64_t size, char** out);
 

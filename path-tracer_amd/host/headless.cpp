@@ -4,7 +4,7 @@
 //
 //   ptr_headless --scene file.{ptrscene,gltf,glb} [--apply-transforms] [--gpu-bvh] --width W --height H --spp N [--max-bounce B] [--min-bounce B]
 //                [--dof 0|1] [--downscale D] [--debug-bvh 0|1] [--pipeline compute|compute.megakernel|compute.wavefront]
-//                [--pos x y z] [--target x y z] [--fov deg] [--aperture a] [--focus f] [--out image.pfm|image.ppm]
+//                [--pos x y z] [--target x y z] [--fov deg] [--aperture a] [--focus f] [--out image.pfm|image.ppm|image.png]
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -16,6 +16,7 @@
 #include "compute-renderpass.hpp"
 #include "gltf.hpp"
 #include "hip-renderer.hpp"
+#include "image.hpp"
 #include "scene.hpp"
 
 namespace {
@@ -24,7 +25,15 @@ float clampf(float x, float lo, float hi) { return x < lo ? lo : (x > hi ? hi : 
 void write_image(const std::string& path, const std::vector<float>& rgba, uint32_t w, uint32_t h) {
     FILE* f = std::fopen(path.c_str(), "wb");
     if (!f) { std::fprintf(stderr, "cannot write %s\n", path.c_str()); std::exit(2); }
-    if (path.size() > 4 && path.substr(path.size() - 4) == ".ppm") {
+    const auto quantise = [](float c) { return (unsigned)(256.0 * clampf(c, 0.f, 0.999f)); };  // write_color(), src/color.cpp:6-14
+    if (path.size() > 4 && path.substr(path.size() - 4) == ".png") {
+        // the same 8-bit values as the .ppm, in a container image viewers open
+        std::vector<uint8_t> rgb((size_t)w * h * 3);
+        for (size_t i = 0; i < (size_t)w * h; i++)
+            for (int k = 0; k < 3; k++) rgb[i * 3 + k] = (uint8_t)quantise(rgba[i * 4 + k]);
+        const std::vector<uint8_t> file = encode_png_rgb8(rgb.data(), w, h);
+        std::fwrite(file.data(), 1, file.size(), f);
+    } else if (path.size() > 4 && path.substr(path.size() - 4) == ".ppm") {
         // the reference's write_color(): 256 * clamp(c, 0, 0.999) (src/color.cpp:6-14)
         std::fprintf(f, "P3\n%u\n%u\n255\n", w, h);
         for (size_t i = 0; i < (size_t)w * h; i++)

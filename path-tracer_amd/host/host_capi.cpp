@@ -175,6 +175,21 @@ int32_t ptrh_image_decode(const uint8_t* bytes, uint64_t size, int32_t* width, i
     }
 }
 
+int32_t ptrh_image_encode_png(const uint8_t* rgb, uint32_t width, uint32_t height, uint8_t** file_out, uint64_t* size_out) {
+    try {
+        if (!rgb || !file_out || !size_out) { g_last_error = "ptrh_image_encode_png: null argument"; return -1; }
+        const std::vector<uint8_t> file = encode_png_rgb8(rgb, width, height);
+        *file_out = (uint8_t*)std::malloc(file.size());
+        if (!*file_out) { g_last_error = "ptrh_image_encode_png: out of memory"; return -1; }
+        std::memcpy(*file_out, file.data(), file.size());
+        *size_out = file.size();
+        return 0;
+    } catch (const std::exception& e) {
+        g_last_error = e.what();
+        return -1;
+    }
+}
+
 int32_t ptrh_json_dump(const char* text, uint64_t size, char** out) {
     try {
         if (!text || !out) { g_last_error = "ptrh_json_dump: null argument"; return -1; }

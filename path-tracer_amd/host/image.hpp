@@ -26,6 +26,9 @@ struct raw_image {
 // RFC 1950 / 1951: zlib stream -> bytes.  `expected_size` (0 = unknown) bounds the output.
 std::vector<uint8_t> zlib_inflate(const uint8_t* src, size_t size, size_t expected_size = 0);
 
+// RGB8 PNG file image (colour type 2, stored deflate blocks, filter 0): lossless and readable everywhere; nothing is compressed.
+std::vector<uint8_t> encode_png_rgb8(const uint8_t* rgb, uint32_t width, uint32_t height);
+
 raw_image decode_png(const uint8_t* bytes, size_t size);
 raw_image decode_jpeg(const uint8_t* bytes, size_t size);
 raw_image decode_image(const uint8_t* bytes, size_t size);  // sniffs the signature

@@ -209,6 +209,50 @@ std::vector<uint8_t> zlib_inflate(const uint8_t* src, size_t size, size_t expect
     return out;
 }
 
+std::vector<uint8_t> encode_png_rgb8(const uint8_t* rgb, uint32_t width, uint32_t height) {
+    if (width == 0 || height == 0) throw image_error("png: empty image");
+    std::vector<uint8_t> out = { 137, 80, 78, 71, 13, 10, 26, 10 };
+    auto be = [](std::vector<uint8_t>& v, uint32_t x) { v.push_back((uint8_t)(x >> 24)); v.push_back((uint8_t)(x >> 16)); v.push_back((uint8_t)(x >> 8)); v.push_back((uint8_t)x); };
+    auto chunk = [&](const char* type, const std::vector<uint8_t>& data) {
+        be(out, (uint32_t)data.size());
+        const size_t start = out.size();
+        out.insert(out.end(), type, type + 4);
+        out.insert(out.end(), data.begin(), data.end());
+        be(out, crc32_png(out.data() + start, out.size() - start));
+    };
+    std::vector<uint8_t> ihdr;
+    be(ihdr, width); be(ihdr, height);
+    ihdr.insert(ihdr.end(), { 8, 2, 0, 0, 0 });
+    chunk("IHDR", ihdr);
+    // scanlines, each led by filter type 0
+    std::vector<uint8_t> raw;
+    raw.reserve(((size_t)width * 3 + 1) * height);
+    for (uint32_t y = 0; y < height; y++) {
+        raw.push_back(0);
+        raw.insert(raw.end(), rgb + (size_t)y * width * 3, rgb + (size_t)(y + 1) * width * 3);
+    }
+    // zlib stream of stored blocks (at most 65535 bytes each) + Adler-32
+    std::vector<uint8_t> z = { 0x78, 0x01 };
+    for (size_t at = 0; at < raw.size();) {
+        const size_t n = raw.size() - at < 65535 ? raw.size() - at : 65535;
+        z.push_back(at + n == raw.size() ? 1 : 0);
+        z.push_back((uint8_t)(n & 0xFF)); z.push_back((uint8_t)(n >> 8));
+        z.push_back((uint8_t)(~n & 0xFF)); z.push_back((uint8_t)((~n >> 8) & 0xFF));
+        z.insert(z.end(), raw.begin() + at, raw.begin() + at + n);
+        at += n;
+    }
+    uint32_t a = 1, b = 0;
+    for (size_t i = 0; i < raw.size();) {
+        const size_t stop = i + 5552 < raw.size() ? i + 5552 : raw.size();
+        for (; i < stop; i++) { a += raw[i]; b += a; }
+        a %= 65521u; b %= 65521u;
+    }
+    be(z, (b << 16) | a);
+    chunk("IDAT", z);
+    chunk("IEND", {});
+    return out;
+}
+
 raw_image decode_png(const uint8_t* bytes, size_t size) {
     static const uint8_t kSignature[8] = { 137, 80, 78, 71, 13, 10, 26, 10 };
     if (size < 8 || std::memcmp(bytes, kSignature, 8) != 0) throw image_error("png: bad signature");

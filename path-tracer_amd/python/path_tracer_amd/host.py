@@ -30,6 +30,7 @@ def lib():
         L.ptrh_scene_texture.argtypes = [vp, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), vp]
         L.ptrh_scene_free.argtypes = [vp]
         L.ptrh_image_decode.argtypes = [vp, C.c_uint64, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(vp)]
+        L.ptrh_image_encode_png.argtypes = [vp, C.c_uint32, C.c_uint32, C.POINTER(vp), C.POINTER(C.c_uint64)]
         L.ptrh_json_dump.argtypes = [C.c_char_p, C.c_uint64, C.POINTER(vp)]
         _lib = L
     return _lib
@@ -103,7 +104,7 @@ def camera(pos, target, v_fov, aspect, aperture, focus, ops=()):
 
 HOST_SYMBOLS = ["ptrh_last_error", "ptrh_sizes", "ptrh_bvh_build", "ptrh_bvh_visit_ranks", "ptrh_bvh_flatten", "ptrh_free", "ptrh_camera",
                 "ptrh_gltf_load", "ptrh_scene_load", "ptrh_scene_counts", "ptrh_scene_arrays", "ptrh_scene_texture", "ptrh_scene_free",
-                "ptrh_image_decode", "ptrh_json_dump"]
+                "ptrh_image_decode", "ptrh_image_encode_png", "ptrh_json_dump"]
 
 # 32-byte material record of a flat scene before upload (texture numbers are 1-based, 0 = none)
 SOURCE_MATERIAL_DTYPE = np.dtype([("base_color", np.float32, 4), ("albedo_tex", np.uint32), ("mr_tex", np.uint32),
@@ -176,6 +177,18 @@ def image_decode(data):
     finally:
         lib().ptrh_free(out)
     return img, ch.value
+
+
+def image_encode_png(rgb):
+    """(h, w, 3) uint8 -> PNG file bytes."""
+    a = np.ascontiguousarray(rgb, dtype=np.uint8)
+    out, size = C.c_void_p(), C.c_uint64()
+    if lib().ptrh_image_encode_png(a.ctypes.data, a.shape[1], a.shape[0], C.byref(out), C.byref(size)) != 0:
+        raise HostError(lib().ptrh_last_error().decode())
+    try:
+        return C.string_at(out, size.value)
+    finally:
+        lib().ptrh_free(out)
 
 
 def json_dump(text):

@@ -131,6 +131,20 @@ def test_png_matches_pillow_on_a_pillow_written_file():
         assert np.array_equal(got, want)
 
 
+def test_png_writer_round_trip():
+    rng = np.random.default_rng(9)
+    for h, w in ((1, 1), (7, 5), (300, 257)):          # the last one needs several stored blocks
+        rgb = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        data = host.image_encode_png(rgb)
+        back, channels = host.image_decode(data)
+        assert channels == 3 and np.array_equal(back[..., :3], rgb) and (back[..., 3] == 255).all()
+        try:
+            from PIL import Image
+            assert np.array_equal(np.asarray(Image.open(io.BytesIO(data)).convert("RGB")), rgb)
+        except ImportError:
+            pass
+
+
 def test_png_errors():
     good = gltf_io.encode_png(np.zeros((4, 4, 4), np.uint32), 6, 8)
     for bad in (good[:-20], good[:40] + bytes([good[40] ^ 1]) + good[41:], b"\x89PNG\r\n\x1a\n" + b"\0" * 30, b"not an image at all"):

@@ -42,8 +42,15 @@ def test_headless_driver_matches_oracle(tmp_path, pipeline, use_flat):
     ppm = str(tmp_path / "out.ppm")
     r = subprocess.run(cmd[:cmd.index("--out") + 1] + [ppm] + cmd[cmd.index("--out") + 2:], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stderr
-    head = open(ppm).read().split()[:4]
-    assert head == ["P3", str(W), str(H), "255"]
+    text = open(ppm).read().split()
+    assert text[:4] == ["P3", str(W), str(H), "255"]
+    # the same 8-bit values in a PNG
+    png = str(tmp_path / "out.png")
+    r = subprocess.run(cmd[:cmd.index("--out") + 1] + [png] + cmd[cmd.index("--out") + 2:], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    from path_tracer_amd import host
+    texels, _ = host.image_decode(open(png, "rb").read())
+    assert np.array_equal(texels[..., :3].reshape(-1), np.array(text[4:], dtype=np.int64).astype(np.uint8))
 
 
 @pytest.mark.parametrize("container", ["gltf", "glb"])
