@@ -298,6 +298,8 @@ __global__ __launch_bounds__(kExtendThreads, 4) void ptr_wf_extend(FlatView fv, 
 // ---- shade ---------------------------------------------------------------------------------------------
 constexpr uint32_t kShadeThreads = 512;
 
+// (Grouping the survivors by the octant of their new direction, so that a traversal wave holds rays that order a
+// node's children alike, was measured: no gain in the traversal, a slower shade step.)
 // Survivors of a 1024-lane block are compacted with ONE atomic on the next queue's counter: ballots give the
 // per-wave counts, lane 0 of the block turns them into offsets.  (A single address sustains only ~90 atomics
 // per microsecond, so per-wave appends would bound the kernel.)
