@@ -31,3 +31,14 @@ def test_host_library_exports_every_declared_entry_point():
     lib = ctypes.CDLL(paths.HOST_LIB)
     missing = [n for n in names if not hasattr(lib, n)]
     assert names and not missing, missing
+
+
+def test_headers_are_plain_c(tmp_path):
+    """The boundary is a C ABI: both headers must compile as C99 on their own (no C++-isms, no torch or HIP types)."""
+    import subprocess
+    from path_tracer_amd import paths
+    src = tmp_path / "abi.c"
+    src.write_text('#include "ptr_hip.h"\n#include "ptr_host.h"\n'
+                   'int use(ptr_ctx* c) { uint8_t k[64] = {0}; return ptr_dispatch(c, "compute", k, 1, 1, 1) + (int)sizeof(ptr_handle); }\n')
+    r = subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-fsyntax-only", "-I", paths.INCLUDE, str(src)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
