@@ -111,11 +111,12 @@ def pmc_traffic(kernel, workload):
         with open(path) as f:
             t = json.load(f)
     except (OSError, ValueError):
-        return None, "no profiles/traffic.json"
+        return None, "no profiles/traffic.json", {}
     rec = t.get("kernels", {}).get(kernel)
     if rec is None or t.get("workload") != workload:
-        return None, "profiles/traffic.json holds no counters for this kernel and workload"
-    return rec["bytes_per_launch"], t.get("note", "")
+        return None, "profiles/traffic.json holds no counters for this kernel and workload", {}
+    extra = {k: rec[k] for k in ("valu_busy", "l2_hit_rate", "l1_hit_rate", "waves_waiting") if k in rec}
+    return rec["bytes_per_launch"], t.get("note", ""), extra
 
 
 def main():
@@ -291,7 +292,7 @@ def main():
                              f"{W}x{H}, 1 spp per step, max_bounce {args.bounces}, min_bounce 1, dof off")
             ks = solo.get(dominant, dict(launches=0, total_ms=0.0))
             solo_bytes = algo_bytes * ks["launches"] / max(1, k["launches"])
-            traffic, traffic_note = pmc_traffic(dominant, line_workload)
+            traffic, traffic_note, counters = pmc_traffic(dominant, line_workload)
             line = {
                 "metric": "Mrays/s", "value": rays_total / elapsed / 1e6, "unit": "Mrays/s",
                 "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
@@ -308,6 +309,8 @@ def main():
                              "bytes_per_unit": {"node": node_bytes, "triangle": tri_bytes},
                              "nodes_per_ray": stats["nodes"] / max(1, stats["rays"]), "triangles_per_ray": stats["triangles"] / max(1, stats["rays"]),
                              "traffic_note": traffic_note,
+                             # from the same counter passes: VALU issue utilisation, cache hit rates, share of wave cycles spent waiting
+                             "counters": counters,
                              # the same kernel with the GPU to itself (one frame in flight): launches of overlapped frames share the CUs
                              "solo": {"avg_launch_ms": ks["total_ms"] / max(1, ks["launches"]),
                                       "achieved": solo_bytes / (ks["total_ms"] * 1e-3) / 1e9 if ks["total_ms"] > 0 else 0.0,

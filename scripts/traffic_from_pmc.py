@@ -34,11 +34,26 @@ def main():
     write, _ = mean_per_kernel(os.path.join(pmc_dir, "write"), "WRITE_SIZE")
     with open(bench_json) as f:
         bench = json.loads(f.read().strip().splitlines()[-1])
+    def counter(pass_name, counter_name):
+        return mean_per_kernel(os.path.join(pmc_dir, pass_name), counter_name)[0]
+    valu, busy = counter("sq1", "SQ_INSTS_VALU"), counter("tcp", "GRBM_GUI_ACTIVE")
+    wait, wave_cycles = counter("sq1", "SQ_WAIT_ANY"), counter("sq1", "SQ_WAVE_CYCLES")
+    hit, miss = counter("tcc", "TCC_HIT_sum"), counter("tcc", "TCC_MISS_sum")
+    l1_req, l1_miss = counter("tcp", "TCP_TOTAL_CACHE_ACCESSES_sum"), counter("tcp", "TCP_TCC_READ_REQ_sum")
     kernels = {}
     for name in fetch:
         fb, wb = fetch[name] * 1024.0, write.get(name, 0.0) * 1024.0
         kernels[name] = dict(fetch_size_kib=fetch[name], write_size_kib=write.get(name, 0.0), launches_sampled=n[name],
                              bytes_per_launch=2.0 * fb + wb)
+        if name in valu and busy.get(name):
+            # a wave64 VALU instruction occupies its SIMD for 4 cycles; 1024 SIMDs; GRBM_GUI_ACTIVE sums the 8 XCDs
+            kernels[name]["valu_busy"] = valu[name] * 4.0 / (1024.0 * busy[name] / 8.0)
+        if name in hit and hit[name] + miss.get(name, 0.0) > 0:
+            kernels[name]["l2_hit_rate"] = hit[name] / (hit[name] + miss[name])
+        if name in l1_req and l1_req[name] > 0:
+            kernels[name]["l1_hit_rate"] = 1.0 - l1_miss.get(name, 0.0) / l1_req[name]
+        if name in wait and wave_cycles.get(name):
+            kernels[name]["waves_waiting"] = wait[name] / wave_cycles[name]
     doc = dict(workload=bench["config"]["workload"], kernels=kernels,
                note="per launch, mean over the launches of a short bench.py run under rocprofv3 --pmc (FETCH_SIZE and WRITE_SIZE in separate "
                     "passes); bytes = 2 x FETCH_SIZE (gfx950 tallies 128-byte requests as 64) + WRITE_SIZE; the doubling is an upper bound for "
