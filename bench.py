@@ -102,6 +102,22 @@ def cpu_baseline(args, sc, nodes, flat, meta, gpu_scene, budget_s):
                        f"{rays} rays in {dt:.1f}s, " + ("flattened BVH" if use_flat else "reference-order threaded BVH"))
 
 
+def lavapipe_probe():
+    """The reference's own shader could only be timed on the host through a CPU Vulkan driver (Mesa lavapipe) plus a GLSL
+    compiler; neither ships in this image.  Reported so that the baseline line says what it is and what it is not."""
+    import ctypes.util
+    import glob
+    import shutil
+    missing = []
+    if not (shutil.which("glslc") or shutil.which("glslangValidator")):
+        missing.append("no GLSL compiler (glslc / glslangValidator)")
+    if not ctypes.util.find_library("vulkan"):
+        missing.append("no libvulkan")
+    if not glob.glob("/usr/share/vulkan/icd.d/*lvp*") and not glob.glob("/etc/vulkan/icd.d/*lvp*"):
+        missing.append("no lavapipe ICD")
+    return "available (not driven by this benchmark)" if not missing else "unavailable: " + ", ".join(missing)
+
+
 def pmc_traffic(kernel, workload):
     """HBM bytes per launch of `kernel` from the committed counter passes of this same command (profiles/traffic.json,
     written by scripts/traffic_from_pmc.py): FETCH_SIZE and WRITE_SIZE come from separate rocprofv3 --pmc runs, so
@@ -320,6 +336,7 @@ def main():
             }
             if world == 1 and args.cpu_seconds > 0:
                 line["cpu_baseline"] = cpu_baseline(args, sc, nodes, flat, meta, gpu, args.cpu_seconds)
+                line["cpu_baseline"]["reference_on_lavapipe"] = lavapipe_probe()
             else:
                 line["cpu_baseline"] = None
             os.write(result_fd, (json.dumps(line) + "\n").encode())
