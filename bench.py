@@ -97,7 +97,14 @@ def cpu_baseline(args, sc, nodes, flat, meta, gpu_scene, budget_s):
         if time.time() - t0 >= budget_s:
             break
     dt = time.time() - t0
-    return dict(value=rays / dt / 1e6, unit="Mrays/s", cores=threads, kind="port",
+    # one thread on a few of the same bands, for the per-core figure
+    single_rays, t1 = 0, time.time()
+    for y in order[:64]:
+        single_rays += o.render(acc, out, rows=(y, y + band), threads=1, use_flat=use_flat)["rays"]
+        if time.time() - t1 >= max(1.0, budget_s * 0.25):
+            break
+    single_dt = time.time() - t1
+    return dict(value=rays / dt / 1e6, unit="Mrays/s", cores=threads, kind="port", single_thread_value=single_rays / single_dt / 1e6,
                 sample=f"{rows_done} of {H} rows ({rows_done // band} bands of {band} rows spread over the frame), sample_index 1, "
                        f"{rays} rays in {dt:.1f}s, " + ("flattened BVH" if use_flat else "reference-order threaded BVH"))
 
