@@ -72,7 +72,7 @@ def build_scene(args, rank):
 
 def cpu_baseline(args, sc, nodes, flat, meta, gpu_scene, budget_s):
     """The oracle (a scalar C port of the reference shader, walking the reference-order tree exactly like the
-    reference) on the host cores, on a bounded sample of the same workload: 4-row bands spread over the frame."""
+    reference) on the host cores, on a bounded sample of the same workload: bands of rows spread over the frame."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import pyoracle
     pyoracle.build()
@@ -84,19 +84,25 @@ def cpu_baseline(args, sc, nodes, flat, meta, gpu_scene, budget_s):
     H, W = args.height, args.width
     acc = np.zeros((H, W, 4), np.float32)
     out = np.zeros_like(acc)
-    band = 4
+    band = 4 * threads                          # the oracle's workers take rows of a call one at a time: four rows each
     starts = list(range(0, H - band + 1, band))
     order = [starts[(i * 37) % len(starts)] for i in range(len(starts))]  # spread over the frame
     rays = 0
     rows_done = 0
     t0 = time.time()
-    for y in order:
-        c = o.render(acc, out, rows=(y, y + band), threads=threads, use_flat=use_flat)
-        rays += c["rays"]
-        rows_done += band
-        if time.time() - t0 >= budget_s:
-            break
+    sample_index = 1
+    while time.time() - t0 < budget_s and sample_index <= 64:       # whole frames, sample after sample, until the budget is used
+        o.set_meta(sample_index=sample_index)
+        for y in order:
+            c = o.render(acc, out, rows=(y, y + band), threads=threads, use_flat=use_flat)
+            rays += c["rays"]
+            rows_done += band
+            if time.time() - t0 >= budget_s:
+                break
+        acc, out = out, acc
+        sample_index += 1
     dt = time.time() - t0
+    o.set_meta(sample_index=1)
     # one thread on a few of the same bands, for the per-core figure
     single_rays, t1 = 0, time.time()
     for y in order[:64]:
@@ -105,7 +111,7 @@ def cpu_baseline(args, sc, nodes, flat, meta, gpu_scene, budget_s):
             break
     single_dt = time.time() - t1
     return dict(value=rays / dt / 1e6, unit="Mrays/s", cores=threads, kind="port", single_thread_value=single_rays / single_dt / 1e6,
-                sample=f"{rows_done} of {H} rows ({rows_done // band} bands of {band} rows spread over the frame), sample_index 1, "
+                sample=f"{rows_done} rows of {H}-row frames ({rows_done // band} bands of {band} rows spread over the frame, sample_index 1..{sample_index - 1}), "
                        f"{rays} rays in {dt:.1f}s, " + ("flattened BVH" if use_flat else "reference-order threaded BVH"))
 
 
