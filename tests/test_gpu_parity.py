@@ -324,6 +324,36 @@ def test_metadata_flags(ctx, pipeline, use_flat, meta_kw):
     assert_same(img, ref, f"{pipeline} {meta_kw}")
 
 
+@pytest.mark.parametrize("pipeline,use_flat", [("compute.megakernel", False), ("compute.wavefront", True)])
+@pytest.mark.parametrize("w,h,meta_kw", [(1, 1, {}), (7, 3, {}), (9, 65, dict(enable_dof=1)), (50, 37, dict(downscale_factor=3)), (33, 20, dict(downscale_factor=5))])
+def test_ragged_image_sizes(ctx, pipeline, use_flat, w, h, meta_kw):
+    """Sizes that are no multiple of the 8x8 workgroup, down to one pixel, and downscale factors that do not divide them."""
+    b = make_bundle("tiny", 0, w, h, max_bounce=3, **meta_kw)
+    img, gs, _, _ = gpu_frames(ctx, b, 2, pipeline)
+    ref, _, _ = oracle_for(b, gs, 2, use_flat=use_flat)
+    assert_same(img, ref, f"{pipeline} {w}x{h} {meta_kw}")
+
+
+def test_dispatch_smaller_and_larger_than_the_image(ctx):
+    """The workgroup count is the caller's: fewer groups than the image leave the rest untouched, more are clipped
+    (compute.comp:265 guards with the metadata's width and height)."""
+    from path_tracer_amd import hip
+    b = make_bundle("tiny", 0, 40, 32, max_bounce=3)
+    full, gs, _, _ = gpu_frames(ctx, b, 1, "compute.wavefront")
+    for pipeline in ("compute.wavefront", "compute.megakernel"):
+        for gx, gy in ((2, 1), (64, 64)):
+            gs.set_meta(b["meta"])
+            loop = hip.FrameLoop(ctx, gs, 40, 32, pipeline)
+            loop.renderpass.set_dispatch_size(gx, gy, 1)
+            loop.frame()
+            img = loop.latest().read()
+            covered = np.zeros((32, 40), bool)
+            covered[:min(32, gy * 8), :min(40, gx * 8)] = True
+            want = full if pipeline == "compute.wavefront" else gpu_frames(ctx, b, 1, pipeline, gpu_scene=gs)[0]
+            assert np.array_equal(img[covered], want[covered]), (pipeline, gx, gy)
+            assert (img[~covered] == 0).all(), (pipeline, gx, gy)
+
+
 def test_debug_bvh_heatmap(ctx):
     b = make_bundle("atrium", 3000, 64, 40, debug_bvh=1)
     img, gs, _, _ = gpu_frames(ctx, b, 1, "compute.megakernel")
