@@ -30,6 +30,13 @@ int32_t ptrh_bvh_visit_ranks(const void* nodes, int64_t node_count, int64_t prim
  * ranks may be NULL (rank = primitive index); threads 0 = automatic. */
 int32_t ptrh_bvh_flatten(const float* positions, int64_t n, const int32_t* ranks, uint32_t threads, void** blob_out,
                          uint64_t* size_out);
+/* bvh::flatten_instances(): the top level over `instance_count` placed copies of one flattened tree -- an extension,
+ * the reference has no instancing (its scene is one triangle soup, src/scene.cpp:84-176).  object_blob is
+ * ptrh_bvh_flatten()'s (or ptr_bvh_build_flat()'s) output; object_to_world holds 12 floats per instance, the three
+ * rows (3x3 part, translation) of an invertible affine matrix.  Returns header | 64-byte nodes | 64-byte instance
+ * records (world-to-object rows, object root) in a malloc'ed blob for ptr_bvh_bind_instances; free with ptrh_free. */
+int32_t ptrh_bvh_flatten_instances(const void* object_blob, uint64_t object_bytes, const float* object_to_world, int64_t instance_count,
+                                   uint32_t threads, void** blob_out, uint64_t* size_out);
 void ptrh_free(void* p);
 
 /* camera::camera + optional set_aspect_ratio / move / rotate_y -- reference: src/camera.cpp:6-57.

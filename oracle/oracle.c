@@ -263,7 +263,7 @@ typedef struct {
 } meta_t; /* 160 bytes */
 
 typedef struct { v3 origin, direction; float min_t, max_t; } ray_t;
-typedef struct { v3 point, barycentrics, geometry_normal; float t; uint32_t primitive_id; } hit_t;
+typedef struct { v3 point, barycentrics, geometry_normal; float t; uint32_t primitive_id; int32_t instance; } hit_t;
 
 static inline void decode_triangle_indices(const orc_frame* f, uint32_t tri, uint32_t out[4]) { /* ray.h:20-30 */
     if (f->index_words == 4) { /* wide extension: plain vertex ids and material id */
@@ -418,26 +418,55 @@ typedef struct {
 static inline float max3_(float a, float b, float c) { return fmax_(fmax_(a, b), c); }
 static inline float min3_(float a, float b, float c) { return fmin_(fmin_(a, b), c); }
 
-int orc_closest_hit_flat(const void* blob, const float origin[3], const float dir[3], float min_t, float max_t,
-                         int32_t* prim_out, float* t_out, float bary_out[3], orc_counters* c) {
+typedef struct {
+    float world_to_object[12];
+    int32_t object_root;
+    int32_t pad[3];
+} flat_instance_t;
+#define FLAT_INSTANCES_MAGIC 0x49525450u
+#define FLAT_INSTANCE_TAG 0x40000000u
+
+typedef struct {
+    float best_t, best_u, best_v;
+    int32_t best_rank, best_prim, best_inst;
+    int hit;
+    uint64_t n_nodes, n_tris;
+} flat_state;
+
+/* The ray below an instance: origin and direction through the rows of world_to_object, each component summed left to
+ * right, the translation last; the direction keeps its length, so t means the same in both spaces. */
+static inline v3 xform_point(const float* m, v3 p) {
+    return V3(((m[0] * p.x + m[1] * p.y) + m[2] * p.z) + m[3], ((m[4] * p.x + m[5] * p.y) + m[6] * p.z) + m[7],
+              ((m[8] * p.x + m[9] * p.y) + m[10] * p.z) + m[11]);
+}
+static inline v3 xform_dir(const float* m, v3 d) {
+    return V3((m[0] * d.x + m[1] * d.y) + m[2] * d.z, (m[4] * d.x + m[5] * d.y) + m[6] * d.z, (m[8] * d.x + m[9] * d.y) + m[10] * d.z);
+}
+/* An object-space normal taken to world space: the transpose of world_to_object (not normalised here). */
+static inline v3 xform_normal(const float* m, v3 n) {
+    return V3((m[0] * n.x + m[4] * n.y) + m[8] * n.z, (m[1] * n.x + m[5] * n.y) + m[9] * n.z, (m[2] * n.x + m[6] * n.y) + m[10] * n.z);
+}
+
+/* One tree of the flattened layout, from reference `root`, for the ray (o, d) of instance `inst` (-1: no instancing).
+ * A tree whose header carries the instances magic has instance leaves: each takes the ray into the object's space
+ * and walks `object_blob` from the instance's root before the top level goes on -- the order in which the kernels'
+ * single stack visits them.  Equal-t ties: the later (instance, rank) pair wins. */
+static void flat_walk(const void* blob, int32_t root, v3 o, v3 d, float min_t, int32_t inst, const void* object_blob, flat_state* s) {
     const flat_header_t* h = (const flat_header_t*)blob;
     const flat_node_t* nodes = (const flat_node_t*)((const uint8_t*)blob + h->nodes_offset);
+    const int top_level = h->magic == FLAT_INSTANCES_MAGIC;
     const flat_tri_t* tris = (const flat_tri_t*)((const uint8_t*)blob + h->triangles_offset);
-    v3 o = V3(origin[0], origin[1], origin[2]), d = V3(dir[0], dir[1], dir[2]);
+    const flat_instance_t* instances = (const flat_instance_t*)((const uint8_t*)blob + h->triangles_offset);
     v3 inv = V3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
     const int neg_x = is_neg(inv.x), neg_y = is_neg(inv.y), neg_z = is_neg(inv.z);
-    float best_t = max_t, best_u = 0, best_v = 0;
-    int32_t best_rank = -1, best_prim = -1;
-    int hit = 0;
     int32_t stack[256];
     int sp = 0;
-    int32_t cur = h->root;
-    uint64_t n_nodes = 0, n_tris = 0;
+    int32_t cur = root;
     const float inf = INFINITY;
     for (;;) {
         if (cur >= 0) {
             const flat_node_t* nd = &nodes[cur];
-            n_nodes++;
+            s->n_nodes++;
             const float Ax = nd->step_x * inv.x, Ay = nd->step_y * inv.y, Az = nd->step_z * inv.z;
             const float Bx = (nd->origin[0] - o.x) * inv.x, By = (nd->origin[1] - o.y) * inv.y, Bz = (nd->origin[2] - o.z) * inv.z;
             const uint32_t near_x = neg_x ? nd->qhi_x : nd->qlo[0], far_x = neg_x ? nd->qlo[0] : nd->qhi_x;
@@ -454,13 +483,13 @@ int orc_closest_hit_flat(const void* blob, const float origin[3], const float di
                 const float ny = fmaf((float)((near_y >> sh) & 0xffu), Ay, By), fy = fmaf((float)((far_y >> sh) & 0xffu), Ay, By);
                 const float nz = fmaf((float)((near_z >> sh) & 0xffu), Az, Bz), fz = fmaf((float)((far_z >> sh) & 0xffu), Az, Bz);
                 const float t0 = fmax_(max3_(nx, ny, nz), min_t);
-                const float t1 = fmin_(min3_(fx, fy, fz), best_t);
+                const float t1 = fmin_(min3_(fx, fy, fz), s->best_t);
                 if (t1 * FLAT_PAD >= t0) key[k] = t0;
             }
             /* sorting network (0,1)(2,3)(0,2)(1,3)(1,2): nearest entry first; misses (+inf) sink to the end */
             static const int net[5][2] = { { 0, 1 }, { 2, 3 }, { 0, 2 }, { 1, 3 }, { 1, 2 } };
-            for (int s = 0; s < 5; s++) {
-                const int a = net[s][0], b = net[s][1];
+            for (int st = 0; st < 5; st++) {
+                const int a = net[st][0], b = net[st][1];
                 if (key[a] > key[b]) {
                     float tk = key[a]; key[a] = key[b]; key[b] = tk;
                     int32_t tr = ref[a]; ref[a] = ref[b]; ref[b] = tr;
@@ -473,12 +502,17 @@ int orc_closest_hit_flat(const void* blob, const float origin[3], const float di
                 cur = ref[0];
                 continue;
             }
+        } else if (top_level) {
+            const uint32_t index = (uint32_t)~cur & ~FLAT_INSTANCE_TAG;
+            const flat_instance_t* in = &instances[index];
+            flat_walk(object_blob, in->object_root, xform_point(in->world_to_object, o), xform_dir(in->world_to_object, d), min_t,
+                      (int32_t)index, NULL, s);
         } else {
             uint32_t ref = (uint32_t)~cur;
             uint32_t first = ref >> 2, count = (ref & 3u) + 1u;
             for (uint32_t k = 0; k < count; k++) {
                 const flat_tri_t* tr = &tris[first + k];
-                n_tris++;
+                s->n_tris++;
                 v3 e1 = V3(tr->e1[0], tr->e1[1], tr->e1[2]), e2 = V3(tr->e2[0], tr->e2[1], tr->e2[2]);
                 v3 n = V3(tr->n[0], tr->n[1], tr->n[2]);
                 v3 ov = sub3(o, V3(tr->p0[0], tr->p0[1], tr->p0[2]));
@@ -487,21 +521,45 @@ int orc_closest_hit_flat(const void* blob, const float origin[3], const float di
                 float u = dd * dot3(neg3(q), e2);
                 float v = dd * dot3(q, e1);
                 float t = dd * dot3(neg3(n), ov);
-                if (u < 0.0f || u > 1.0f || v < 0.0f || u + v > 1.0f || t < min_t || t > best_t) continue;
+                if (u < 0.0f || u > 1.0f || v < 0.0f || u + v > 1.0f || t < min_t || t > s->best_t) continue;
                 if (is_nan(t) || is_nan(u) || is_nan(v)) continue;
-                if (hit && t == best_t && tr->rank < best_rank) continue;
-                hit = 1; best_t = t; best_u = u; best_v = v; best_rank = tr->rank; best_prim = tr->primitive_id;
+                if (s->hit && t == s->best_t && (inst < s->best_inst || (inst == s->best_inst && tr->rank < s->best_rank))) continue;
+                s->hit = 1; s->best_t = t; s->best_u = u; s->best_v = v; s->best_rank = tr->rank; s->best_prim = tr->primitive_id;
+                s->best_inst = inst;
             }
         }
         if (sp == 0) break;
         cur = stack[--sp];
     }
-    if (c) { c->rays++; c->nodes += n_nodes; c->triangles += n_tris; }
-    if (hit) {
-        *prim_out = best_prim; *t_out = best_t;
-        bary_out[0] = 1.0f - best_u - best_v; bary_out[1] = best_u; bary_out[2] = best_v;
+}
+
+/* Closest hit over a flattened tree, or over the instances in `instances_blob` of the tree in `blob` when that is
+ * given; *inst_out (optional) receives the instance hit, -1 without instancing. */
+int orc_closest_hit_two_level(const void* blob, const void* instances_blob, const float origin[3], const float dir[3], float min_t,
+                              float max_t, int32_t* prim_out, int32_t* inst_out, float* t_out, float bary_out[3], orc_counters* c) {
+    flat_state s;
+    memset(&s, 0, sizeof s);
+    s.best_t = max_t; s.best_rank = -1; s.best_prim = -1; s.best_inst = -1;
+    const v3 o = V3(origin[0], origin[1], origin[2]), d = V3(dir[0], dir[1], dir[2]);
+    if (instances_blob) flat_walk(instances_blob, ((const flat_header_t*)instances_blob)->root, o, d, min_t, -1, blob, &s);
+    else flat_walk(blob, ((const flat_header_t*)blob)->root, o, d, min_t, -1, NULL, &s);
+    if (c) { c->rays++; c->nodes += s.n_nodes; c->triangles += s.n_tris; }
+    if (s.hit) {
+        *prim_out = s.best_prim; *t_out = s.best_t;
+        if (inst_out) *inst_out = s.best_inst;
+        bary_out[0] = 1.0f - s.best_u - s.best_v; bary_out[1] = s.best_u; bary_out[2] = s.best_v;
     }
-    return hit;
+    return s.hit;
+}
+
+int orc_closest_hit_flat(const void* blob, const float origin[3], const float dir[3], float min_t, float max_t,
+                         int32_t* prim_out, float* t_out, float bary_out[3], orc_counters* c) {
+    return orc_closest_hit_two_level(blob, NULL, origin, dir, min_t, max_t, prim_out, NULL, t_out, bary_out, c);
+}
+
+static inline const float* instance_rows(const orc_frame* f, int32_t inst) {
+    const flat_header_t* h = (const flat_header_t*)f->flat_instances;
+    return ((const flat_instance_t*)((const uint8_t*)f->flat_instances + h->triangles_offset))[inst].world_to_object;
 }
 
 /* hit_node() semantics on top of the flattened layout: same outputs as hit_node (geometry normal from the
@@ -509,13 +567,16 @@ int orc_closest_hit_flat(const void* blob, const float origin[3], const float di
 static int hit_node_flat(const orc_frame* f, ray_t r, hit_t* info, orc_counters* c) {
     int32_t prim; float t, bary[3];
     float o[3] = { r.origin.x, r.origin.y, r.origin.z }, d[3] = { r.direction.x, r.direction.y, r.direction.z };
-    if (!orc_closest_hit_flat(f->flat_bvh, o, d, r.min_t, r.max_t, &prim, &t, bary, c)) return 0;
+    int32_t inst = -1;
+    if (!orc_closest_hit_two_level(f->flat_bvh, f->flat_instances, o, d, r.min_t, r.max_t, &prim, &inst, &t, bary, c)) return 0;
     uint32_t idx[4];
     decode_triangle_indices(f, (uint32_t)prim, idx);
     v3 p0 = load3(f->positions, idx[0]), p1 = load3(f->positions, idx[1]), p2 = load3(f->positions, idx[2]);
     info->t = t;
     info->barycentrics = V3(bary[0], bary[1], bary[2]);
     info->geometry_normal = normalize3(cross3(sub3(p1, p0), sub3(p2, p0)));
+    info->instance = inst;
+    if (inst >= 0) info->geometry_normal = normalize3(xform_normal(instance_rows(f, inst), info->geometry_normal));
     info->primitive_id = (uint32_t)prim;
     info->point = add3(r.origin, scale3(r.direction, t));
     return 1;
@@ -565,6 +626,11 @@ static v4 sample_bindless(const orc_frame* f, uint32_t texture_id, float u, floa
 /* ------------------------------------------------------------------------------------------------
  * compute.comp:124-245
  * ---------------------------------------------------------------------------------------------- */
+static uint32_t captured_primitive(const orc_frame* f, const hit_t* info) {
+    if (!(f->use_flat && f->flat_instances) || info->instance < 0) return info->primitive_id;
+    return (uint32_t)info->instance * ((const flat_header_t*)f->flat_bvh)->triangle_count + info->primitive_id;
+}
+
 #define BRDF_DIFFUSE 1u
 #define BRDF_SPECULAR 2u
 
@@ -580,7 +646,7 @@ static v3 ray_color(const orc_frame* f, const meta_t* m, ray_t r, uint32_t seed,
         int any_nan = 0;
         int hit = f->use_flat ? hit_node_flat(f, r, &info, c) : hit_node(f, r, &info, c, &any_nan);
         if (bounce < 2 && aov_prim) {
-            aov_prim[bounce] = hit ? (any_nan ? -2 : (int32_t)info.primitive_id) : -1;
+            aov_prim[bounce] = hit ? (any_nan ? -2 : (int32_t)captured_primitive(f, &info)) : -1;
             aov_t[bounce] = hit ? info.t : 0.0f;
         }
         if (!hit) return scale3(throughput, 1.0f);
@@ -598,6 +664,9 @@ static v3 ray_color(const orc_frame* f, const meta_t* m, ray_t r, uint32_t seed,
 
         v2 uv = interp2(tuv, info.barycentrics);
         v3 shading_normal = normalize3(interp3(nrm, info.barycentrics));
+        /* below an instance the normals are the object's: world_to_object transposed takes them to world space */
+        if (f->use_flat && f->flat_instances && info.instance >= 0)
+            shading_normal = normalize3(xform_normal(instance_rows(f, info.instance), shading_normal));
 
         v4 albedo = sample_bindless(f, mat->albedo_tex, uv.x, uv.y);
         v3 diffuse_color = mul3(srgb_to_linear(V3(albedo.x, albedo.y, albedo.z)),

@@ -77,6 +77,8 @@ typedef struct {
     uint32_t seed_sample_index;  /* 0: the per-pixel seed uses the metadata's sample_index (compute.comp:270); otherwise this value
                                     seeds the pixel while the metadata's sample_index still weights the accumulation: the sample
                                     partition over several GPUs, where a GPU's k-th frame draws global sample (k-1)*world+rank+1 */
+    const void* flat_instances;  /* optional top level over placed copies of flat_bvh (header|nodes|instance records); used with
+                                    use_flat.  Captured primitive ids then read instance * triangle_count + primitive. */
 } orc_frame;
 
 /* compute.comp main() over the rows [y0, y1) of the dispatch, `threads` worker threads. */
@@ -112,6 +114,9 @@ int orc_closest_hit(const orc_frame* f, const float origin[3], const float dir[3
 /* closest hit over the flattened layout (same conventions) */
 int orc_closest_hit_flat(const void* flat_bvh, const float origin[3], const float dir[3], float min_t, float max_t,
                          int32_t* prim, float* t, float bary[3], orc_counters* c);
+/* closest hit over the instances in `flat_instances` of the tree `flat_bvh` (flat_instances NULL: the tree alone) */
+int orc_closest_hit_two_level(const void* flat_bvh, const void* flat_instances, const float origin[3], const float dir[3], float min_t,
+                              float max_t, int32_t* prim, int32_t* inst, float* t, float bary[3], orc_counters* c);
 /* hit_aabbs(): number of inner boxes hit (debug heat-map) */
 uint32_t orc_hit_aabbs(const orc_frame* f, const float origin[3], const float dir[3], float min_t, float max_t);
 

@@ -32,7 +32,8 @@ class Frame(C.Structure):
                 ("positions", C.c_void_p), ("normals", C.c_void_p), ("uvs", C.c_void_p), ("materials", C.c_void_p),
                 ("textures", C.POINTER(Texture)), ("texture_count", C.c_uint32), ("accumulation", Image),
                 ("output", Image), ("aov_prim", C.c_void_p), ("aov_t", C.c_void_p), ("flat_bvh", C.c_void_p),
-                ("use_flat", C.c_int32), ("index_words", C.c_uint32), ("seed_sample_index", C.c_uint32)]
+                ("use_flat", C.c_int32), ("index_words", C.c_uint32), ("seed_sample_index", C.c_uint32),
+                ("flat_instances", C.c_void_p)]
 
 
 def build(force=False):
@@ -77,6 +78,7 @@ def lib():
         L.orc_camera_ray.argtypes = [fp, C.c_int32, C.c_int32, C.c_uint32, fp, fp]
         L.orc_closest_hit.argtypes = [C.POINTER(Frame), fp, fp, C.c_float, C.c_float, fp, fp, fp, C.POINTER(Counters)]
         L.orc_closest_hit_flat.argtypes = [fp, fp, fp, C.c_float, C.c_float, fp, fp, fp, C.POINTER(Counters)]
+        L.orc_closest_hit_two_level.argtypes = [fp, fp, fp, fp, C.c_float, C.c_float, fp, fp, fp, fp, C.POINTER(Counters)]
         L.orc_hit_aabbs.restype = C.c_uint32
         L.orc_hit_aabbs.argtypes = [C.POINTER(Frame), fp, fp, C.c_float, C.c_float]
         _lib = L
@@ -108,6 +110,7 @@ class OracleScene:
         assert self.materials.nbytes % 48 == 0
         self.textures = [None if t is None else np.ascontiguousarray(t, dtype=np.uint8) for t in arrays["textures"]]
         self.flat = None if arrays.get("flat") is None else np.ascontiguousarray(arrays["flat"], dtype=np.uint8)
+        self.instances = None if arrays.get("flat_instances") is None else np.ascontiguousarray(arrays["flat_instances"], dtype=np.uint8)
         self._tex = (Texture * max(1, len(self.textures)))()
         for i, t in enumerate(self.textures):
             if t is not None:
@@ -145,6 +148,8 @@ class OracleScene:
             assert self.flat is not None
             f.flat_bvh = self.flat.ctypes.data
             f.use_flat = 1
+            if self.instances is not None:
+                f.flat_instances = self.instances.ctypes.data
         return f
 
     def render(self, acc, out, rows=None, threads=None, aov=None, use_flat=False):

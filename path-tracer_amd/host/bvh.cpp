@@ -500,14 +500,19 @@ void quantise_axis(float node_lo, float node_hi, const float* lo, const float* h
 
 }  // namespace
 
-std::vector<uint8_t> bvh::flatten(const std::vector<triangle>& tris, const std::vector<int32_t>& ranks, unsigned threads) {
-    if (tris.empty()) throw bvh_build_error("flatten: no triangles");
-    if (tris.size() >= (1u << 29)) throw bvh_build_error("flatten: too many triangles for the leaf reference encoding");
-    if (!ranks.empty() && ranks.size() != tris.size()) throw bvh_build_error("flatten: ranks/triangles size mismatch");
+namespace {
 
-    std::vector<int32_t> order;
-    const std::vector<sah_node> nodes = build_sah(tris, order, 4, threads);
+// The SAH tree collapsed to 4 children per node and numbered in depth-first pre-order, with its leaves' items laid
+// out in leaf order and the traversal stack it needs.
+struct wide_layout {
+    std::vector<wide_node> wide;
+    std::vector<uint32_t> wide_of;      // sah id of each wide node
+    std::vector<int32_t> wide_index;    // wide index of each sah inner node that survived the collapse
+    std::vector<uint32_t> leaf_first;   // first item of each sah leaf, in leaf order
+    uint32_t item_count = 0, stack_need = 0;
+};
 
+wide_layout collapse_tree(const std::vector<sah_node>& nodes) {
     // Collapse to 4 children per node: starting from a node's two children, the inner child with the largest
     // surface area is replaced by its own two children until there are four (or only leaves are left).
     auto collapse = [&](uint32_t id) {
@@ -530,62 +535,42 @@ std::vector<uint8_t> bvh::flatten(const std::vector<triangle>& tris, const std::
         return w;
     };
 
-    // Pass 1 (depth-first pre-order): number the wide nodes, place the triangles in leaf order, bound the stack.
-    std::vector<int32_t> wide_index(nodes.size(), -1);
-    std::vector<uint32_t> leaf_first(nodes.size(), 0);
-    std::vector<wide_node> wide;
-    std::vector<uint32_t> wide_of;  // sah id of each wide node
-    uint32_t tri_cursor = 0, stack_need = 0;
+    // Depth-first pre-order: number the wide nodes, place the items in leaf order, bound the stack.
+    wide_layout L;
+    L.wide_index.assign(nodes.size(), -1);
+    L.leaf_first.assign(nodes.size(), 0);
     if (nodes[0].left < 0) {
-        leaf_first[0] = 0;
-        tri_cursor = nodes[0].count;
-    } else {
-        struct visit { uint32_t id, pending; };  // pending = stack entries that can be live when this node is entered
-        std::vector<visit> stack{ { 0, 0 } };
-        while (!stack.empty()) {
-            const visit v = stack.back();
-            stack.pop_back();
-            if (nodes[v.id].left < 0) {
-                leaf_first[v.id] = tri_cursor;
-                tri_cursor += nodes[v.id].count;
-                continue;
-            }
-            const wide_node w = collapse(v.id);
-            wide_index[v.id] = (int32_t)wide.size();
-            wide.push_back(w);
-            wide_of.push_back(v.id);
-            const uint32_t pending = v.pending + (w.count - 1);
-            stack_need = std::max(stack_need, pending);
-            for (int k = (int)w.count - 1; k >= 0; k--) stack.push_back({ (uint32_t)w.child[k], pending });
-        }
+        L.leaf_first[0] = 0;
+        L.item_count = nodes[0].count;
+        return L;
     }
-    if (stack_need > FLAT_BVH_MAX_DEPTH) throw bvh_build_error("flatten: tree needs a deeper traversal stack than the kernels have");
-
-    const size_t nodes_bytes = wide.size() * sizeof(flat_bvh_node);
-    const size_t tris_bytes = tris.size() * sizeof(flat_bvh_triangle);
-    std::vector<uint8_t> blob(sizeof(flat_bvh_header) + nodes_bytes + tris_bytes, 0);
-    auto* header = reinterpret_cast<flat_bvh_header*>(blob.data());
-    auto* out_nodes = reinterpret_cast<flat_bvh_node*>(blob.data() + sizeof(flat_bvh_header));
-    auto* out_tris = reinterpret_cast<flat_bvh_triangle*>(blob.data() + sizeof(flat_bvh_header) + nodes_bytes);
-
-    auto reference_to = [&](int32_t id) -> int32_t {
-        const sah_node& nd = nodes[id];
-        if (nd.left >= 0) return wide_index[id];
-        return ~(int32_t)((leaf_first[id] << 2) | (nd.count - 1));
-    };
-
-    for (size_t id = 0; id < nodes.size(); id++) {
-        const sah_node& nd = nodes[id];
-        if (nd.left >= 0) continue;
-        // leaves of collapsed-away inner nodes are still reached through their wide ancestor
-        for (uint32_t k = 0; k < nd.count; k++) {
-            const int32_t prim = order[nd.first + k];
-            fill_flat_triangle(out_tris[leaf_first[id] + k], tris[prim], prim, ranks.empty() ? prim : ranks[prim]);
+    struct visit { uint32_t id, pending; };  // pending = stack entries that can be live when this node is entered
+    std::vector<visit> stack{ { 0, 0 } };
+    while (!stack.empty()) {
+        const visit v = stack.back();
+        stack.pop_back();
+        if (nodes[v.id].left < 0) {
+            L.leaf_first[v.id] = L.item_count;
+            L.item_count += nodes[v.id].count;
+            continue;
         }
+        const wide_node w = collapse(v.id);
+        L.wide_index[v.id] = (int32_t)L.wide.size();
+        L.wide.push_back(w);
+        L.wide_of.push_back(v.id);
+        const uint32_t pending = v.pending + (w.count - 1);
+        L.stack_need = std::max(L.stack_need, pending);
+        for (int k = (int)w.count - 1; k >= 0; k--) stack.push_back({ (uint32_t)w.child[k], pending });
     }
-    for (size_t wi = 0; wi < wide.size(); wi++) {
-        const wide_node& w = wide[wi];
-        const aabb& box = nodes[wide_of[wi]].box;
+    return L;
+}
+
+// Writes the 64-byte nodes of a collapsed tree; `reference_to(sah id)` names a child (inner index or leaf reference).
+template <class ReferenceTo>
+void write_wide_nodes(const std::vector<sah_node>& nodes, const wide_layout& L, flat_bvh_node* out_nodes, ReferenceTo reference_to) {
+    for (size_t wi = 0; wi < L.wide.size(); wi++) {
+        const wide_node& w = L.wide[wi];
+        const aabb& box = nodes[L.wide_of[wi]].box;
         flat_bvh_node& fn = out_nodes[wi];
         uint32_t biased[3];
         uint8_t qlo[3][4] = {}, qhi[3][4] = {};
@@ -602,11 +587,143 @@ std::vector<uint8_t> bvh::flatten(const std::vector<triangle>& tris, const std::
         fn.qlo[0] = pack(qlo[0]); fn.qlo[1] = pack(qlo[1]); fn.qlo[2] = pack(qlo[2]);
         fn.qhi_x = pack(qhi[0]); fn.qhi_y = pack(qhi[1]); fn.qhi_z = pack(qhi[2]);
     }
+}
+
+}  // namespace
+
+std::vector<uint8_t> bvh::flatten(const std::vector<triangle>& tris, const std::vector<int32_t>& ranks, unsigned threads) {
+    if (tris.empty()) throw bvh_build_error("flatten: no triangles");
+    if (tris.size() >= (1u << 29)) throw bvh_build_error("flatten: too many triangles for the leaf reference encoding");
+    if (!ranks.empty() && ranks.size() != tris.size()) throw bvh_build_error("flatten: ranks/triangles size mismatch");
+
+    std::vector<int32_t> order;
+    const std::vector<sah_node> nodes = build_sah(tris, order, 4, threads);
+    const wide_layout L = collapse_tree(nodes);
+    if (L.stack_need > FLAT_BVH_MAX_DEPTH) throw bvh_build_error("flatten: tree needs a deeper traversal stack than the kernels have");
+
+    const size_t nodes_bytes = L.wide.size() * sizeof(flat_bvh_node);
+    const size_t tris_bytes = tris.size() * sizeof(flat_bvh_triangle);
+    std::vector<uint8_t> blob(sizeof(flat_bvh_header) + nodes_bytes + tris_bytes, 0);
+    auto* header = reinterpret_cast<flat_bvh_header*>(blob.data());
+    auto* out_nodes = reinterpret_cast<flat_bvh_node*>(blob.data() + sizeof(flat_bvh_header));
+    auto* out_tris = reinterpret_cast<flat_bvh_triangle*>(blob.data() + sizeof(flat_bvh_header) + nodes_bytes);
+
+    auto reference_to = [&](int32_t id) -> int32_t {
+        const sah_node& nd = nodes[id];
+        if (nd.left >= 0) return L.wide_index[id];
+        return ~(int32_t)((L.leaf_first[id] << 2) | (nd.count - 1));
+    };
+
+    for (size_t id = 0; id < nodes.size(); id++) {
+        const sah_node& nd = nodes[id];
+        if (nd.left >= 0) continue;
+        // leaves of collapsed-away inner nodes are still reached through their wide ancestor
+        for (uint32_t k = 0; k < nd.count; k++) {
+            const int32_t prim = order[nd.first + k];
+            fill_flat_triangle(out_tris[L.leaf_first[id] + k], tris[prim], prim, ranks.empty() ? prim : ranks[prim]);
+        }
+    }
+    write_wide_nodes(nodes, L, out_nodes, reference_to);
 
     header->magic = FLAT_BVH_MAGIC;
     header->version = FLAT_BVH_VERSION;
-    header->node_count = (uint32_t)wide.size();
+    header->node_count = (uint32_t)L.wide.size();
     header->triangle_count = (uint32_t)tris.size();
+    header->nodes_offset = sizeof(flat_bvh_header);
+    header->triangles_offset = sizeof(flat_bvh_header) + nodes_bytes;
+    header->root = reference_to(0);
+    header->max_depth = L.stack_need;
+    for (int a = 0; a < 3; a++) { header->scene_min[a] = nodes[0].box.minimum.v[a]; header->scene_max[a] = nodes[0].box.maximum.v[a]; }
+    return blob;
+}
+
+// ---- top level over instances of one flattened tree ----------------------------------------------------------
+namespace {
+// world-to-object of an affine object-to-world matrix (rows of 4: 3x3 part, translation), in double
+bool invert_affine(const float* m, double inv[12]) {
+    const double a = m[0], b = m[1], c = m[2], d = m[4], e = m[5], f = m[6], g = m[8], h = m[9], i = m[10];
+    const double det = a * (e * i - f * h) - b * (d * i - f * g) + c * (d * h - e * g);
+    if (!(std::fabs(det) > 0.0) || !std::isfinite(det)) return false;
+    const double r = 1.0 / det;
+    inv[0] = (e * i - f * h) * r; inv[1] = (c * h - b * i) * r; inv[2] = (b * f - c * e) * r;
+    inv[4] = (f * g - d * i) * r; inv[5] = (a * i - c * g) * r; inv[6] = (c * d - a * f) * r;
+    inv[8] = (d * h - e * g) * r; inv[9] = (b * g - a * h) * r; inv[10] = (a * e - b * d) * r;
+    for (int row = 0; row < 3; row++)
+        inv[row * 4 + 3] = -(inv[row * 4] * (double)m[3] + inv[row * 4 + 1] * (double)m[7] + inv[row * 4 + 2] * (double)m[11]);
+    for (int k = 0; k < 12; k++) if (!std::isfinite(inv[k])) return false;
+    return true;
+}
+}  // namespace
+
+std::vector<uint8_t> bvh::flatten_instances(const std::vector<uint8_t>& object_blob, const std::vector<float>& object_to_world, unsigned threads) {
+    if (object_blob.size() < sizeof(flat_bvh_header)) throw bvh_build_error("flatten_instances: no object tree");
+    const auto* object_header = reinterpret_cast<const flat_bvh_header*>(object_blob.data());
+    if (object_header->magic != FLAT_BVH_MAGIC || object_header->version != FLAT_BVH_VERSION) throw bvh_build_error("flatten_instances: not a flattened tree");
+    if (object_to_world.empty() || object_to_world.size() % 12 != 0) throw bvh_build_error("flatten_instances: transforms are 12 floats each");
+    const size_t count = object_to_world.size() / 12;
+    if (count >= FLAT_INSTANCE_LIMIT) throw bvh_build_error("flatten_instances: too many instances for the leaf reference encoding");
+    if (object_header->triangle_count >= (1u << 28)) throw bvh_build_error("flatten_instances: object tree too large to be instanced");
+
+    // World box of each instance: the eight corners of the object's box through the matrix (double), rounded
+    // outwards and padded by 2^-18 of the box's size and distance from the origin -- room for the rounding of the
+    // object-space ray (a few 2^-24 of the same magnitudes) that the traversal below the instance sees.
+    std::vector<flat_bvh_instance> records(count);
+    std::vector<triangle> proxies(count);  // a "triangle" spanning the box: same bounds, centroid near the middle
+    for (size_t k = 0; k < count; k++) {
+        const float* m = &object_to_world[k * 12];
+        for (int j = 0; j < 12; j++) if (!std::isfinite(m[j])) throw bvh_build_error("flatten_instances: non-finite transform");
+        double inv[12];
+        if (!invert_affine(m, inv)) throw bvh_build_error("flatten_instances: singular transform");
+        double lo[3] = { 1e300, 1e300, 1e300 }, hi[3] = { -1e300, -1e300, -1e300 };
+        for (int corner = 0; corner < 8; corner++) {
+            const double p[3] = { (corner & 1) ? object_header->scene_max[0] : object_header->scene_min[0],
+                                  (corner & 2) ? object_header->scene_max[1] : object_header->scene_min[1],
+                                  (corner & 4) ? object_header->scene_max[2] : object_header->scene_min[2] };
+            for (int a = 0; a < 3; a++) {
+                const double w = (double)m[a * 4] * p[0] + (double)m[a * 4 + 1] * p[1] + (double)m[a * 4 + 2] * p[2] + (double)m[a * 4 + 3];
+                lo[a] = std::min(lo[a], w);
+                hi[a] = std::max(hi[a], w);
+            }
+        }
+        double magnitude = 0.0;
+        for (int a = 0; a < 3; a++) magnitude = std::max({ magnitude, std::fabs(lo[a]), std::fabs(hi[a]), hi[a] - lo[a] });
+        const double pad = magnitude * 3.814697265625e-06 + 1e-30;  // 2^-18
+        vec3 bmin, bmax;
+        for (int a = 0; a < 3; a++) {
+            bmin.v[a] = std::nextafter((float)(lo[a] - pad), -std::numeric_limits<float>::infinity());
+            bmax.v[a] = std::nextafter((float)(hi[a] + pad), std::numeric_limits<float>::infinity());
+            if (!std::isfinite(bmin.v[a]) || !std::isfinite(bmax.v[a])) throw bvh_build_error("flatten_instances: instance out of the fp32 range");
+        }
+        proxies[k] = triangle(bmin, bmax, (bmin + bmax) / 2.f);
+        flat_bvh_instance& r = records[k];
+        for (int j = 0; j < 12; j++) r.world_to_object[j] = (float)inv[j];
+        r.object_root = object_header->root;
+        r.pad[0] = r.pad[1] = r.pad[2] = 0;
+    }
+
+    std::vector<int32_t> order;
+    const std::vector<sah_node> nodes = build_sah(proxies, order, 1, threads);
+    const wide_layout L = collapse_tree(nodes);
+    // one entry marks the way back out of an instance; the object's own stack sits on top of it
+    const uint32_t stack_need = L.stack_need + 1u + object_header->max_depth;
+    if (stack_need > FLAT_BVH_MAX_DEPTH) throw bvh_build_error("flatten_instances: the two trees need a deeper traversal stack than the kernels have");
+
+    const size_t nodes_bytes = L.wide.size() * sizeof(flat_bvh_node);
+    std::vector<uint8_t> blob(sizeof(flat_bvh_header) + nodes_bytes + count * sizeof(flat_bvh_instance), 0);
+    auto* header = reinterpret_cast<flat_bvh_header*>(blob.data());
+    auto* out_nodes = reinterpret_cast<flat_bvh_node*>(blob.data() + sizeof(flat_bvh_header));
+    auto reference_to = [&](int32_t id) -> int32_t {
+        const sah_node& nd = nodes[id];
+        if (nd.left >= 0) return L.wide_index[id];
+        return ~(int32_t)(FLAT_INSTANCE_TAG | (uint32_t)order[nd.first]);  // one instance per leaf, records stay in the caller's order
+    };
+    write_wide_nodes(nodes, L, out_nodes, reference_to);
+    std::memcpy(blob.data() + sizeof(flat_bvh_header) + nodes_bytes, records.data(), count * sizeof(flat_bvh_instance));
+
+    header->magic = FLAT_INSTANCES_MAGIC;
+    header->version = FLAT_BVH_VERSION;
+    header->node_count = (uint32_t)L.wide.size();
+    header->triangle_count = (uint32_t)count;
     header->nodes_offset = sizeof(flat_bvh_header);
     header->triangles_offset = sizeof(flat_bvh_header) + nodes_bytes;
     header->root = reference_to(0);

@@ -76,6 +76,22 @@ constexpr uint32_t FLAT_BVH_VERSION = 2;          // 4-wide nodes with quantised
 constexpr uint32_t FLAT_BVH_MAX_DEPTH = 254;      // most stack entries a layout may ask for (the kernels size their spill area from the header)
 constexpr int32_t FLAT_BVH_EMPTY_CHILD = INT32_MIN;
 
+// ---- two levels: instances of one flattened tree ------------------------------------------------------------
+// A second blob of the same shape (header | nodes | records) whose leaves name instances instead of triangles:
+// ~ref = FLAT_INSTANCE_TAG | instance index, one instance per leaf.  Its boxes are in world space; below an instance
+// the traversal goes on in the object's space with the ray taken through `world_to_object` (the direction is not
+// renormalised, so a distance t means the same on both sides).  header.triangle_count holds the instance count,
+// header.triangles_offset the offset of the records, header.max_depth the stack of both levels together.
+struct flat_bvh_instance {
+    float world_to_object[12];   // three rows of (3x3 part, translation)
+    int32_t object_root;         // root reference of the instanced tree
+    int32_t pad[3];
+};
+static_assert(sizeof(flat_bvh_instance) == 64, "instance record is one 64-byte line");
+constexpr uint32_t FLAT_INSTANCES_MAGIC = 0x49525450u;  // "PTRI"
+constexpr uint32_t FLAT_INSTANCE_TAG = 0x40000000u;      // set in ~ref of an instance leaf; triangle leaves of an instanced tree stay below it
+constexpr uint32_t FLAT_INSTANCE_LIMIT = 0x3ffffff0u;    // instance indices above are reserved for the kernels' markers
+
 class bvh_build_error : public std::runtime_error {
 public:
     using std::runtime_error::runtime_error;
@@ -100,6 +116,11 @@ public:
     // Returns one contiguous blob: header | nodes | triangles.
     static std::vector<uint8_t> flatten(const std::vector<triangle>& triangles, const std::vector<int32_t>& ranks,
                                         unsigned threads = 0);
+
+    // Top level over `object_to_world.size() / 12` instances (rows of an affine object-to-world matrix each) of the
+    // tree in `object_blob`.  Returns header | nodes | instance records.
+    static std::vector<uint8_t> flatten_instances(const std::vector<uint8_t>& object_blob, const std::vector<float>& object_to_world,
+                                                  unsigned threads = 0);
 
     std::vector<triangle>& triangles;
 

@@ -85,6 +85,26 @@ int32_t ptrh_bvh_flatten(const float* positions, int64_t n, const int32_t* ranks
     }
 }
 
+int32_t ptrh_bvh_flatten_instances(const void* object_blob, uint64_t object_bytes, const float* object_to_world, int64_t instance_count,
+                                   uint32_t threads, void** blob_out, uint64_t* size_out) {
+    try {
+        if (!object_blob || !object_to_world || !blob_out || !size_out) { g_last_error = "ptrh_bvh_flatten_instances: null argument"; return -1; }
+        if (instance_count <= 0) { g_last_error = "ptrh_bvh_flatten_instances: instance_count must be positive"; return -1; }
+        const std::vector<uint8_t> object((const uint8_t*)object_blob, (const uint8_t*)object_blob + object_bytes);
+        const std::vector<float> transforms(object_to_world, object_to_world + instance_count * 12);
+        const std::vector<uint8_t> blob = bvh::flatten_instances(object, transforms, threads);
+        void* mem = std::malloc(blob.size());
+        if (!mem) { g_last_error = "ptrh_bvh_flatten_instances: out of memory"; return -1; }
+        std::memcpy(mem, blob.data(), blob.size());
+        *blob_out = mem;
+        *size_out = blob.size();
+        return 0;
+    } catch (const std::exception& e) {
+        g_last_error = e.what();
+        return -1;
+    }
+}
+
 void ptrh_free(void* p) { std::free(p); }
 
 void ptrh_camera(const float pos[3], const float target[3], float v_fov, float aspect, float aperture, float focus_dist,

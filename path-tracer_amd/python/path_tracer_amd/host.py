@@ -19,6 +19,9 @@ def lib():
         L.ptrh_bvh_visit_ranks.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]
         L.ptrh_bvh_flatten.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p),
                                        C.POINTER(C.c_uint64)]
+        L.ptrh_bvh_flatten_instances.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_int64, C.c_uint32, C.POINTER(C.c_void_p),
+                                                 C.POINTER(C.c_uint64)]
+        L.ptrh_bvh_flatten_instances.restype = C.c_int32
         L.ptrh_free.argtypes = [C.c_void_p]
         L.ptrh_camera.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p,
                                   C.c_int32, C.c_void_p]
@@ -81,6 +84,23 @@ def bvh_flatten(triangles, ranks=None, threads=0):
     return blob
 
 
+def bvh_flatten_instances(object_blob, object_to_world, threads=0):
+    """Top level over placed copies of one flattened tree.  object_to_world: (n, 3, 4) affine matrices.
+    Returns the blob (uint8 array): 64-byte header | 64-byte nodes | 64-byte instance records."""
+    obj = np.ascontiguousarray(object_blob, dtype=np.uint8)
+    m = np.ascontiguousarray(object_to_world, dtype=np.float32).reshape(-1, 12)
+    ptr = C.c_void_p()
+    size = C.c_uint64()
+    rc = lib().ptrh_bvh_flatten_instances(obj.ctypes.data, obj.size, m.ctypes.data, m.shape[0], threads, C.byref(ptr), C.byref(size))
+    if rc != 0:
+        raise HostError(lib().ptrh_last_error().decode())
+    try:
+        blob = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint8)), shape=(size.value,)).copy()
+    finally:
+        lib().ptrh_free(ptr)
+    return blob
+
+
 def flat_header(blob):
     u = blob[:64].view(np.uint32)
     q = blob[:64].view(np.uint64)
@@ -102,7 +122,7 @@ def camera(pos, target, v_fov, aspect, aperture, focus, ops=()):
     return out
 
 
-HOST_SYMBOLS = ["ptrh_last_error", "ptrh_sizes", "ptrh_bvh_build", "ptrh_bvh_visit_ranks", "ptrh_bvh_flatten", "ptrh_free", "ptrh_camera",
+HOST_SYMBOLS = ["ptrh_last_error", "ptrh_sizes", "ptrh_bvh_build", "ptrh_bvh_visit_ranks", "ptrh_bvh_flatten", "ptrh_bvh_flatten_instances", "ptrh_free", "ptrh_camera",
                 "ptrh_gltf_load", "ptrh_scene_load", "ptrh_scene_counts", "ptrh_scene_arrays", "ptrh_scene_texture", "ptrh_scene_free",
                 "ptrh_image_decode", "ptrh_image_encode_png", "ptrh_json_dump"]
 

@@ -381,6 +381,50 @@ def instance_grid(scene, nx, nz, spacing=None):
     return out
 
 
+def grid_transforms(scene, nx, nz, spacing=None):
+    """The placements of instance_grid() as (nx * nz, 3, 4) object-to-world matrices, in the same order."""
+    P = np.asarray(scene["positions"], np.float32).reshape(-1, 3)
+    extent = P.max(axis=0) - P.min(axis=0)
+    if spacing is None:
+        spacing = (float(extent[0]) * 1.02, float(extent[2]) * 1.02)
+    m = np.zeros((nx * nz, 3, 4), np.float32)
+    m[:, 0, 0] = m[:, 1, 1] = m[:, 2, 2] = 1.0
+    k = 0
+    for ix in range(nx):
+        for iz in range(nz):
+            m[k, :, 3] = np.array([(ix - (nx - 1) / 2.0) * spacing[0], 0.0, (iz - (nz - 1) / 2.0) * spacing[1]], np.float32)
+            k += 1
+    return m
+
+
+def expand_instances(scene, object_to_world):
+    """The placed copies of `scene` written out as ONE flat scene in the 4-word index layout: positions through the
+    matrices, normals through their inverse transposes.  Triangle k of copy i becomes triangle i * T + k."""
+    base = widen_indices(scene) if int(scene.get("index_words", 3)) == 3 else scene
+    M = np.asarray(object_to_world, np.float64).reshape(-1, 3, 4)
+    P = np.asarray(base["positions"], np.float64).reshape(-1, 3)
+    N = np.asarray(base["normals"], np.float64).reshape(-1, 3)
+    U = np.asarray(base["uvs"], np.float32).reshape(-1, 2)
+    I = np.asarray(base["indices"], np.uint32).reshape(-1, 4)
+    copies, nv = M.shape[0], P.shape[0]
+    assert copies * nv < 2 ** 32
+    positions = np.empty((copies, nv, 3), np.float32)
+    normals = np.empty((copies, nv, 3), np.float32)
+    indices = np.empty((copies, I.shape[0], 4), np.uint32)
+    for k in range(copies):
+        A = M[k, :, :3]
+        positions[k] = (P @ A.T + M[k, :, 3]).astype(np.float32)
+        n = N @ np.linalg.inv(A)            # rows: (A^-T n)^T
+        normals[k] = (n / np.maximum(np.linalg.norm(n, axis=1, keepdims=True), 1e-30)).astype(np.float32)
+        indices[k, :, :3] = I[:, :3] + np.uint32(k * nv)
+        indices[k, :, 3] = I[:, 3]
+    positions = positions.reshape(-1, 3)
+    out = dict(base, positions=positions.reshape(-1), normals=normals.reshape(-1), uvs=np.tile(U, (copies, 1)).reshape(-1),
+               indices=indices.reshape(-1), index_words=4, kind=f"{scene.get('kind', 'scene')} x{copies}")
+    out["triangles"] = np.ascontiguousarray(positions[indices.reshape(-1, 4)[:, :3].reshape(-1)].reshape(-1, 9))
+    return out
+
+
 def pack_metadata(camera_block, width, height, max_bounce=3, min_bounce=1, sample_index=1, enable_dof=0, debug_bvh=0,
                   downscale_factor=1):
     """160-byte scene metadata: the 128-byte camera followed by eight 32-bit words
