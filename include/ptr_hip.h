@@ -76,6 +76,16 @@ int ptr_image_address(ptr_ctx* ctx, ptr_handle image, uint64_t* device_address);
  *      the wavefront kernels over the flattened layout.  flat = 0 removes the association. ---- */
 int ptr_bvh_bind_flat(ptr_ctx* ctx, ptr_handle threaded_nodes, ptr_handle flat);
 
+/* Placed copies of a flattened layout (instancing) -- an extension: the reference's scene is one triangle soup
+ * (src/scene.cpp:84-176), so a scene of repeated objects is written out copy by copy there.  `instances` holds the blob
+ * bvh::flatten_instances() / ptrh_bvh_flatten_instances() emit for the layout in `flat`: header | 64-byte nodes over the
+ * copies' world-space boxes | one 64-byte record per copy (three rows of the world-to-object matrix, the object's root).
+ * A later wavefront dispatch over `flat` walks that top level first and enters `flat` once per copy the ray reaches, with
+ * the ray taken into the object's space; normals come back through the transposed matrix.  The index / vertex / material
+ * buffers of the constant block stay the object's own.  A captured primitive id (ptr_set_capture) reads
+ * copy * triangle_count + primitive.  instances = 0 removes the association.  The megakernel path does not instance. */
+int ptr_bvh_bind_instances(ptr_ctx* ctx, ptr_handle flat, ptr_handle instances);
+
 /* ---- dispatch: ComputeRenderpass::execute -> vkCmdPushConstants(64 B) + vkCmdDispatch
  *      (src/compute-renderpass.cpp:51-63, src/vk-api.cpp:1090-1092,1171-1177).
  *      kernel: the reference's shader names, "compute" (shaders/compute.comp) or "tonemapping"

@@ -27,6 +27,10 @@ struct BufferRec {
     uint64_t generation = 0;       // context-wide write counter at this buffer's creation / last write
     ptr::FlatView flat_view{};
     uint32_t flat_nodes = 0, flat_triangles = 0;  // counts from the parsed header
+    ptr_handle instances = 0;      // on a flattened-layout buffer: the top level over its placed copies, if any
+    bool top_view_valid = false;   // this buffer holds such a top level whose header was parsed
+    ptr::InstanceView top_view{};
+    uint32_t top_nodes = 0, top_depth = 0;
 };
 struct ImageRec {
     void* ptr = nullptr;
@@ -81,7 +85,7 @@ struct ptr_ctx {
         uint64_t synced_epoch = 0;       // value of write_epoch when this slot's stream last waited for the context's stream
         ptr::WavefrontScratch scratch{};
         void* scratch_block = nullptr;
-        ptr_handle reads[8] = {};        // buffers the slot's last frame reads (hazard check of later writes)
+        ptr_handle reads[9] = {};        // buffers the slot's last frame reads (hazard check of later writes)
     };
     FrameSlot slots[kMaxFrameSlots];
     int next_slot = 0;
@@ -255,8 +259,8 @@ int ensure_scratch(ptr_ctx* c, ptr_ctx::FrameSlot& slot, uint32_t capacity, uint
     const size_t cap = ((size_t)capacity + 255) & ~(size_t)255;
     const uint32_t extend_blocks = (uint32_t)c->cu_count * (uint32_t)c->opt_extend_blocks_per_cu;
     const size_t spill_words = (size_t)extend_blocks * (ptr::kExtendThreads / 64) * spill * 64;
-    // 2 generations x 3 records of 4 words, hits + samples (4 words each), counters, spill
-    const size_t words = cap * (2 * 12 + 8) + 64 + spill_words;
+    // 2 generations x 3 records of 4 words, hits + samples (4 words each), the hit's instance, counters, spill
+    const size_t words = cap * (2 * 12 + 8 + 1) + 64 + spill_words;
     PTR_HIP_CHECK(c, hipMalloc(&slot.scratch_block, words * 4));
     uint32_t* p = (uint32_t*)slot.scratch_block;
     auto take = [&](size_t n) { uint32_t* r = p; p += n; return r; };
@@ -268,6 +272,7 @@ int ensure_scratch(ptr_ctx* c, ptr_ctx::FrameSlot& slot, uint32_t capacity, uint
         s.ray_d[g] = (float4*)take(cap * 4);
         s.path_t[g] = (float4*)take(cap * 4);
     }
+    s.hit_instance = (int32_t*)take(cap);
     s.counters = take(64);
     s.stack_spill = (int32_t*)take(spill_words);
     s.capacity = (uint32_t)cap;
@@ -366,6 +371,9 @@ int validate_scene(ptr_ctx* c, const uint64_t addr[7], const ptr_handle handles[
     for (int i = 1; i < 7; i++) { key[i - 1] = addr[i]; key[5 + i] = c->buffers[handles[i]].generation; }
     key[12] = flat_buf ? flat_buf->generation : 0;
     key[13] = (uint64_t)c->opt_index_words | (wavefront ? 16u : 0u);
+    BufferRec* top_buf = wavefront && flat_buf && flat_buf->instances ? find_buffer(c, flat_buf->instances) : nullptr;
+    key[14] = top_buf ? top_buf->generation : 0;
+    key[15] = top_buf ? (uint64_t)flat_buf->instances : 0;
     for (const auto& v : c->validated) if (v.used && !memcmp(v.key, key, sizeof key)) return PTR_OK;
 
     auto bytes_from = [&](int i) { const BufferRec& b = c->buffers[handles[i]]; return (uint64_t)(uintptr_t)b.ptr + b.size - addr[i]; };
@@ -379,16 +387,22 @@ int validate_scene(ptr_ctx* c, const uint64_t addr[7], const ptr_handle handles[
     if (triangles && threaded > 2 * triangles - 1) threaded = 2 * triangles - 1;
     if (triangles > 0xffffffffull || threaded > 0xffffffffull) return fail(c, PTR_E_RANGE, "scene: buffers larger than 2^32 records");
     if (!c->d_validate) PTR_HIP_CHECK(c, hipMalloc((void**)&c->d_validate, 16));
-    const ptr::FlatView* fv = wavefront && flat_buf ? &flat_buf->flat_view : nullptr;
+    ptr::FlatView view{};
+    const ptr::FlatView* fv = nullptr;
+    if (wavefront && flat_buf) {
+        view = flat_buf->flat_view;
+        view.top = top_buf ? top_buf->top_view : ptr::InstanceView{};
+        fv = &view;
+    }
     PTR_HIP_CHECK(c, ptr::launch_validate_scene(c->stream, sv, (uint32_t)triangles, (uint32_t)threaded, fv, fv ? flat_buf->flat_nodes : 0u,
-                                                fv ? flat_buf->flat_triangles : 0u, c->d_validate));
+                                                fv ? flat_buf->flat_triangles : 0u, top_buf ? top_buf->top_nodes : 0u, c->d_validate));
     uint32_t out[4];
     PTR_HIP_CHECK(c, hipMemcpyAsync(out, c->d_validate, sizeof out, hipMemcpyDeviceToHost, c->stream));
     PTR_HIP_CHECK(c, hipStreamSynchronize(c->stream));
     if (triangles && out[0] >= vertices) return fail(c, PTR_E_RANGE, "scene: the index buffer names vertex %u, the vertex buffers hold %llu", out[0], (unsigned long long)vertices);
     if (triangles && out[1] >= materials) return fail(c, PTR_E_RANGE, "scene: the index buffer names material %u, the material buffer holds %llu", out[1], (unsigned long long)materials);
     if (out[2]) return fail(c, PTR_E_RANGE, "scene: %u links or primitive ids of the bvh nodes point outside the node / index buffers", out[2]);
-    if (out[3]) return fail(c, PTR_E_RANGE, "scene: %u child references or primitive ids of the flattened layout point outside it", out[3]);
+    if (out[3]) return fail(c, PTR_E_RANGE, "scene: %u child references or primitive ids of the flattened layout%s point outside it", out[3], top_buf ? " or of its instances" : "");
     ptr_ctx::Validated& slot = c->validated[c->validated_next];
     c->validated_next = (c->validated_next + 1) % 4;
     memcpy(slot.key, key, sizeof key);
@@ -472,7 +486,41 @@ int dispatch_compute(ptr_ctx* c, const uint8_t constants[64], uint32_t gx, uint3
         flat_buf->flat_triangles = hd.triangle_count;
         flat_buf->flat_view_valid = true;
     }
-    const ptr::FlatView fv = flat_buf->flat_view;
+    ptr::FlatView fv = flat_buf->flat_view;
+    BufferRec* top_buf = nullptr;
+    if (flat_buf->instances) {  // placed copies of this layout: the top level is walked first
+        top_buf = find_buffer(c, flat_buf->instances);
+        if (!top_buf) return fail(c, PTR_E_STATE, "instances: the buffer bound with ptr_bvh_bind_instances is gone");
+        if (!top_buf->top_view_valid) {
+            struct Header { uint32_t magic, version, node_count, instance_count; uint64_t nodes_offset, records_offset; int32_t root; uint32_t max_depth; float bounds[6]; } hd;
+            if (top_buf->size < sizeof hd) return fail(c, PTR_E_STATE, "instances: blob shorter than its header");
+            PTR_HIP_CHECK(c, hipMemcpyAsync(&hd, top_buf->ptr, sizeof hd, hipMemcpyDeviceToHost, c->stream));
+            PTR_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+            if (hd.magic != 0x49525450u || hd.version != 2u) return fail(c, PTR_E_STATE, "instances: bad magic/version");
+            if ((hd.nodes_offset & 63u) || (hd.records_offset & 63u)) return fail(c, PTR_E_STATE, "instances: sections are not 64-byte aligned");
+            if (hd.nodes_offset + (uint64_t)hd.node_count * 64 > top_buf->size || hd.records_offset + (uint64_t)hd.instance_count * 64 > top_buf->size)
+                return fail(c, PTR_E_STATE, "instances: sections exceed the buffer");
+            if (hd.instance_count == 0 || hd.instance_count >= 0x3ffffff0u) return fail(c, PTR_E_STATE, "instances: instance count out of range");
+            if (hd.max_depth > ptr::kStackMax) return fail(c, PTR_E_STATE, "instances: needs a traversal stack of %u entries, %u at most", hd.max_depth, ptr::kStackMax);
+            if (hd.root >= 0 ? (uint32_t)hd.root >= hd.node_count
+                             : (((uint32_t)~hd.root & ptr::kInstanceTag) == 0u || ((uint32_t)~hd.root & ~ptr::kInstanceTag) >= hd.instance_count))
+                return fail(c, PTR_E_STATE, "instances: root reference out of range");
+            top_buf->top_view.nodes = (const float4*)((const uint8_t*)top_buf->ptr + hd.nodes_offset);
+            top_buf->top_view.records = (const float4*)((const uint8_t*)top_buf->ptr + hd.records_offset);
+            top_buf->top_view.root = hd.root;
+            top_buf->top_view.count = hd.instance_count;
+            top_buf->top_nodes = hd.node_count;
+            top_buf->top_depth = hd.max_depth;
+            top_buf->top_view_valid = true;
+        }
+        if (flat_buf->flat_triangles >= (1u << 28)) return fail(c, PTR_E_RANGE, "instances: the instanced layout holds 2^28 triangles or more");
+        if (top_buf->top_depth < fv.max_depth + 1u) return fail(c, PTR_E_STATE, "instances: the stack bound in the header does not cover the instanced layout");
+        fv.top = top_buf->top_view;
+        fv.max_depth = top_buf->top_depth;
+        sv.instance_records = fv.top.records;
+        sv.instance_count = fv.top.count;
+        sv.object_triangles = flat_buf->flat_triangles;
+    }
     if ((rc = validate_scene(c, k.addr, handles, sv, flat_buf, true))) return rc;
     if ((rc = ensure_shade_records(c, k.addr, handles, &sv))) return rc;
 
@@ -503,6 +551,7 @@ int dispatch_compute(ptr_ctx* c, const uint8_t constants[64], uint32_t gx, uint3
         uint64_t newest = c->shared_epoch;
         for (int i = 1; i < 7; i++) if (c->buffers[handles[i]].generation > newest) newest = c->buffers[handles[i]].generation;
         if (flat_buf->generation > newest) newest = flat_buf->generation;
+        if (top_buf && top_buf->generation > newest) newest = top_buf->generation;
         if (newest > slot.synced_epoch) {
             PTR_HIP_CHECK(c, hipEventRecord(slot.ready, c->stream));
             PTR_HIP_CHECK(c, hipStreamWaitEvent(ts, slot.ready, 0));
@@ -534,6 +583,7 @@ int dispatch_compute(ptr_ctx* c, const uint8_t constants[64], uint32_t gx, uint3
         slot.in_flight = true;
         for (int i = 0; i < 7; i++) slot.reads[i] = i == 0 ? 0 : handles[i];  // the metadata travels by value
         slot.reads[7] = bvh_buf->flat;
+        slot.reads[8] = flat_buf->instances;
         c->next_slot = (c->next_slot + 1) % c->opt_frames_in_flight;
     }
     return PTR_OK;
@@ -649,7 +699,7 @@ int ptr_buffer_destroy(ptr_ctx* c, ptr_handle h) {
     PTR_HIP_CHECK(c, hipStreamSynchronize(c->stream));
     PTR_HIP_CHECK(c, hipFree(b->ptr));
     *b = BufferRec();
-    for (auto& o : c->buffers) if (o.flat == h) o.flat = 0;
+    for (auto& o : c->buffers) { if (o.flat == h) o.flat = 0; if (o.instances == h) o.instances = 0; }
     if (c->capture == h) c->capture = 0;
     return PTR_OK;
 }
@@ -665,6 +715,7 @@ int ptr_buffer_write(ptr_ctx* c, ptr_handle h, const void* data, size_t offset, 
     if (frame_reads(c, h) && (rc = drain_frames(c))) return rc;  // a frame in flight still reads this buffer
     if (!b->shadow.empty()) memcpy(b->shadow.data() + offset, data, size);
     b->flat_view_valid = false;
+    b->top_view_valid = false;
     b->generation = ++c->write_epoch;
     if (size <= kShadowLimit && c->stage) {
         const int slot = c->stage_next;
@@ -840,6 +891,22 @@ int ptr_bvh_bind_flat(ptr_ctx* c, ptr_handle threaded_nodes, ptr_handle flat) {
     int rc = bind_device(c); if (rc) return rc;
     if ((rc = drain_frames(c))) return rc;
     b->flat = flat;
+    return PTR_OK;
+}
+
+int ptr_bvh_bind_instances(ptr_ctx* c, ptr_handle flat, ptr_handle instances) {
+    if (!c) return PTR_E_INVALID;
+    BufferRec* f = find_buffer(c, flat);
+    if (!f) return fail(c, PTR_E_INVALID, "ptr_bvh_bind_instances: unknown flat buffer %u", flat);
+    if (instances != 0) {
+        BufferRec* t = find_buffer(c, instances);
+        if (!t) return fail(c, PTR_E_INVALID, "ptr_bvh_bind_instances: unknown instance buffer %u", instances);
+        if (t->size < 64) return fail(c, PTR_E_INVALID, "ptr_bvh_bind_instances: instance buffer shorter than the 64-byte header");
+        if (instances == flat) return fail(c, PTR_E_INVALID, "ptr_bvh_bind_instances: the instance buffer cannot be the flat buffer itself");
+    }
+    int rc = bind_device(c); if (rc) return rc;
+    if ((rc = drain_frames(c))) return rc;
+    f->instances = instances;
     return PTR_OK;
 }
 

@@ -57,10 +57,28 @@ struct SceneView {
     uint32_t index_words;      // 3: the reference's packed index words; 4: v0, v1, v2, material as plain words
     const float4* shade_records;  // optional: kShadeRecordVec4 float4 per triangle, see ShadeInputs / gather_shade_inputs
     uint32_t shade_record_count;
+    const float4* instance_records;  // optional (two-level scenes): 4 float4 per instance, rows of world-to-object first
+    uint32_t instance_count;
+    uint32_t object_triangles;       // two-level scenes: captured primitive ids read instance * object_triangles + primitive
 };
 
 struct Ray { f3 origin, dir; float min_t, max_t; };
-struct Hit { float t, u, v; int32_t prim; };  // prim < 0: miss
+struct Hit { float t, u, v; int32_t prim; int32_t inst = -1; };  // prim < 0: miss; inst >= 0: the placed copy that was hit
+
+// ---- placed copies: the ray below an instance, normals on the way back ------------------------------------------------
+// Rows of world-to-object (3x3 part, translation), each component summed left to right, the translation last.  The
+// direction keeps its length, so a distance t means the same in both spaces.
+PTR_DEV f3 xform_point(float4 r0, float4 r1, float4 r2, f3 p) {
+    return mk3(((r0.x * p.x + r0.y * p.y) + r0.z * p.z) + r0.w, ((r1.x * p.x + r1.y * p.y) + r1.z * p.z) + r1.w,
+               ((r2.x * p.x + r2.y * p.y) + r2.z * p.z) + r2.w);
+}
+PTR_DEV f3 xform_dir(float4 r0, float4 r1, float4 r2, f3 d) {
+    return mk3((r0.x * d.x + r0.y * d.y) + r0.z * d.z, (r1.x * d.x + r1.y * d.y) + r1.z * d.z, (r2.x * d.x + r2.y * d.y) + r2.z * d.z);
+}
+// object-space normal to world space: the transpose of world-to-object (not normalised here)
+PTR_DEV f3 xform_normal(float4 r0, float4 r1, float4 r2, f3 n) {
+    return mk3((r0.x * n.x + r1.x * n.y) + r2.x * n.z, (r0.y * n.x + r1.y * n.y) + r2.y * n.z, (r0.z * n.x + r1.z * n.y) + r2.z * n.z);
+}
 
 // ---- rand.h:1-12 -------------------------------------------------------------------------------------
 PTR_DEV uint32_t pcg_hash(uint32_t& seed) {
@@ -319,6 +337,13 @@ PTR_DEV bool shade_bounce(const SceneView& sv, uint32_t bounce, uint32_t min_bou
     const f3 point = r.origin + r.dir * hit.t;
 
     f3 shading_normal = normalize(((in.n0 * bary.x) + (in.n1 * bary.y)) + (in.n2 * bary.z));
+    if (sv.instance_records && hit.inst >= 0) {
+        if ((uint32_t)hit.inst >= sv.instance_count) return false;
+        const float4* rec = sv.instance_records + 4 * (size_t)hit.inst;
+        const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2];
+        geometry_normal = normalize(xform_normal(r0, r1, r2, geometry_normal));
+        shading_normal = normalize(xform_normal(r0, r1, r2, shading_normal));
+    }
     const float tu = (in.uv0.x * bary.x + in.uv1.x * bary.y) + in.uv2.x * bary.z;
     const float tv = (in.uv0.y * bary.x + in.uv1.y * bary.y) + in.uv2.y * bary.z;
 

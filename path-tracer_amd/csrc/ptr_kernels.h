@@ -9,13 +9,25 @@
 
 namespace ptr {
 
+// Top level over placed copies of a flattened BVH (the blob bvh::flatten_instances() emits), as device pointers.
+struct InstanceView {
+    const float4* nodes;      // 4 x float4 per 64-byte node, boxes in world space; nullptr = no instancing
+    const float4* records;    // 4 x float4 per instance: three rows of world-to-object, then (object root, -, -, -)
+    int32_t root;
+    uint32_t count;
+};
+
 // Flattened BVH (the blob bvh::flatten() emits), as device pointers.
 struct FlatView {
     const float4* nodes;      // 4 x float4 per 64-byte node
     const float4* triangles;  // 4 x float4 per 64-byte triangle record
     int32_t root;
-    uint32_t max_depth;
+    uint32_t max_depth;       // stack entries a traversal can need (both levels together when `top` is set)
+    InstanceView top;
 };
+
+constexpr uint32_t kInstanceTag = 0x40000000u;     // set in ~reference of an instance leaf of the top level
+constexpr uint32_t kLeaveInstance = 0x3ffffffeu;   // instance index of the stack entry that marks the way back to world space
 
 // Scratch of the wavefront pipeline, owned by the context, sized for `capacity` paths.
 struct WavefrontScratch {
@@ -25,6 +37,7 @@ struct WavefrontScratch {
     float4* ray_d[2];       // direction.xyz, RNG state (bits)
     float4* path_t[2];      // throughput.xyz, unused
     float4* hits;           // t, u, v, prim (bits)
+    int32_t* hit_instance;  // instance of the hit (two-level scenes only)
     float4* samples;        // per pixel: the sample's colour (w unused)
     uint32_t* counters;     // [0..15]: live paths entering bounce b; [16..31]: fetch cursors of the extend kernel
     int32_t* stack_spill;   // traversal stack overflow area of the persistent extend grid
@@ -67,9 +80,10 @@ size_t flat_build_blob_bytes(uint32_t triangle_count);
 hipError_t build_flat_bvh(hipStream_t s, const SceneView& sv, uint32_t triangle_count, uint32_t vertex_count, void* blob, size_t blob_bytes, int* status);
 
 // Contents check of the buffers a "compute" dispatch dereferences (ptr_kernels_validate.hip).  out4 (device, 4 words):
-// max vertex id, max material id, violations in the threaded nodes, violations in the flattened layout.
+// max vertex id, max material id, violations in the threaded nodes, violations in the flattened layout (and in the top
+// level over its copies, fv->top, when there is one).
 hipError_t launch_validate_scene(hipStream_t s, const SceneView& sv, uint32_t triangle_count, uint32_t threaded_nodes, const FlatView* fv,
-                                 uint32_t flat_nodes, uint32_t flat_triangles, uint32_t* out4);
+                                 uint32_t flat_nodes, uint32_t flat_triangles, uint32_t top_nodes, uint32_t* out4);
 
 // Per-function test kernel (ptr_kernels_unit.hip): index of `name` (< 0 if unknown) with its record sizes in 32-bit words.
 int unit_function_lookup(const char* name, uint32_t* in_words, uint32_t* out_words);

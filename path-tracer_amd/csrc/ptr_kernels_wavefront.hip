@@ -127,7 +127,10 @@ constexpr int32_t kTraversalDone = INT32_MIN;  // never a leaf reference: triang
 //   * The grid is the same for every launch of a frame.  Sharing a short queue among fewer waves (so that each keeps
 //     ~300 rays and drains less) was measured: slower at every setting -- parallelism beats lane utilisation here.
 //   * Per-lane stack: kStackLds entries in LDS (lane-interleaved, conflict-free), deeper entries in global memory.
-template <bool STATS, int REFILL, int LEAF_WEIGHT, bool LEAF_ALL, int INNER_REPS>
+//   * TWO_LEVEL: the tree in fv.top is walked first; its leaves name placed copies of the tree in fv.  A lane that
+//     reaches one takes its ray into the object's space, stacks a marker and goes on at the object's root; when the
+//     marker pops, the world-space ray is read back from the queue.  Both trees share the lane's one stack.
+template <bool STATS, int REFILL, int LEAF_WEIGHT, bool LEAF_ALL, int INNER_REPS, bool TWO_LEVEL>
 __global__ __launch_bounds__(kExtendThreads, 4) void ptr_wf_extend(FlatView fv, WavefrontScratch w, uint32_t gen, uint32_t slot_b,
                                                                 unsigned long long* stats) {
     __shared__ int32_t lds_stack[(kExtendThreads / 64) * kStackLds * 64];
@@ -153,6 +156,7 @@ __global__ __launch_bounds__(kExtendThreads, 4) void ptr_wf_extend(FlatView fv, 
     bool neg_x = false, neg_y = false, neg_z = false;  // sign bits of 1/d: which plane of a slab is the entry
     float best_t = 1e15f, best_u = 0.0f, best_v = 0.0f;
     int32_t best_rank = -1, best_prim = -1;
+    int32_t cur_inst = -1, best_inst = -1;       // TWO_LEVEL: the copy the lane is inside (-1: top level), the copy of the best hit
     int32_t cur = kTraversalDone;
     uint32_t sp = 0u;
 
@@ -173,7 +177,8 @@ __global__ __launch_bounds__(kExtendThreads, 4) void ptr_wf_extend(FlatView fv, 
                         inv = mk3(rcp(d.x), rcp(d.y), rcp(d.z));
                         neg_x = (as_u32(inv.x) >> 31) != 0u; neg_y = (as_u32(inv.y) >> 31) != 0u; neg_z = (as_u32(inv.z) >> 31) != 0u;
                         best_t = 1e15f; best_u = 0.0f; best_v = 0.0f; best_rank = -1; best_prim = -1;
-                        cur = fv.root; sp = 0u;
+                        cur = TWO_LEVEL ? fv.top.root : fv.root; sp = 0u;
+                        cur_inst = -1; best_inst = -1;
                         if (STATS) n_rays++;
                     }
                 }
@@ -198,10 +203,11 @@ __global__ __launch_bounds__(kExtendThreads, 4) void ptr_wf_extend(FlatView fv, 
         #pragma unroll 1
         for (int rep = 0; rep < INNER_REPS; rep++)
         if (!leaf_turn && slot != kInvalidPixel && cur >= 0) {
-            const float4 q0 = fv.nodes[4 * cur];                      // origin.xyz, step.x
-            const int4 refs = ((const int4*)fv.nodes)[4 * cur + 1];
-            const uint4 qa = ((const uint4*)fv.nodes)[4 * cur + 2];  // lo.x lo.y lo.z hi.x
-            const uint4 qb = ((const uint4*)fv.nodes)[4 * cur + 3];  // hi.y hi.z step.y step.z
+            const float4* level_nodes = (TWO_LEVEL && cur_inst < 0) ? fv.top.nodes : fv.nodes;
+            const float4 q0 = level_nodes[4 * cur];                      // origin.xyz, step.x
+            const int4 refs = ((const int4*)level_nodes)[4 * cur + 1];
+            const uint4 qa = ((const uint4*)level_nodes)[4 * cur + 2];  // lo.x lo.y lo.z hi.x
+            const uint4 qb = ((const uint4*)level_nodes)[4 * cur + 3];  // hi.y hi.z step.y step.z
             if (STATS) n_nodes++;
             const f3 A = mk3(q0.w * inv.x, __uint_as_float(qb.z) * inv.y, __uint_as_float(qb.w) * inv.z);
             const f3 B = mk3((q0.x - o.x) * inv.x, (q0.y - o.y) * inv.y, (q0.z - o.z) * inv.z);
@@ -242,9 +248,39 @@ __global__ __launch_bounds__(kExtendThreads, 4) void ptr_wf_extend(FlatView fv, 
         }
 
         if (leaf_turn && at_leaf) {
+            uint32_t ref = (uint32_t)~cur;
+            if (TWO_LEVEL && (ref & kInstanceTag) != 0u) {
+                const uint32_t index = ref & ~kInstanceTag;
+                if (index == kLeaveInstance) {
+                    // the object is done: back to the world-space ray, then on with the top level
+                    const float4 ro = w.ray_o[gen][slot], rd = w.ray_d[gen][slot];
+                    o = mk3(ro.x, ro.y, ro.z);
+                    d = mk3(rd.x, rd.y, rd.z);
+                    cur_inst = -1;
+                    if (sp == 0u) {
+                        cur = kTraversalDone;
+                    } else {
+                        sp--;
+                        cur = stack_pop(my_lds, my_spill, sp);
+                    }
+                } else {
+                    const float4* rec = fv.top.records + 4 * (size_t)index;
+                    const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2];
+                    const int32_t object_root = __float_as_int(rec[3].x);
+                    const f3 wo = o, wd = d;
+                    o = xform_point(r0, r1, r2, wo);
+                    d = xform_dir(r0, r1, r2, wd);
+                    cur_inst = (int32_t)index;
+                    const int32_t marker = ~(int32_t)(kInstanceTag | kLeaveInstance);
+                    if (sp < kStackLds) my_lds[sp * 64u] = marker; else my_spill[(sp - kStackLds) * 64u] = marker;
+                    sp++;
+                    cur = object_root;
+                }
+                inv = mk3(rcp(d.x), rcp(d.y), rcp(d.z));
+                neg_x = (as_u32(inv.x) >> 31) != 0u; neg_y = (as_u32(inv.y) >> 31) != 0u; neg_z = (as_u32(inv.z) >> 31) != 0u;
+            } else {
             // LEAF_ALL: every triangle of the lane's leaf in this turn; otherwise ONE triangle, the rest of the leaf
             // stays encoded in `cur` for the next leaf turn (lanes with short leaves get back to inner nodes sooner)
-            uint32_t ref = (uint32_t)~cur;
             for (;;) {
                 const uint32_t first = ref >> 2, remaining = ref & 3u;  // triangles left after this one
                 const float4* tr = fv.triangles + 4 * (size_t)first;
@@ -259,8 +295,11 @@ __global__ __launch_bounds__(kExtendThreads, 4) void ptr_wf_extend(FlatView fv, 
                 const float t = dd * dot(-n, ov);
                 const bool reject = u < 0.0f || u > 1.0f || v < 0.0f || u + v > 1.0f || t < min_t || t > best_t || t != t || u != u || v != v;
                 const int32_t rank = __float_as_int(a.w);
-                if (!reject && !(best_prim >= 0 && t == best_t && rank < best_rank)) {
+                // equal t: the later (copy, rank) pair wins
+                const bool earlier = TWO_LEVEL ? (cur_inst < best_inst || (cur_inst == best_inst && rank < best_rank)) : rank < best_rank;
+                if (!reject && !(best_prim >= 0 && t == best_t && earlier)) {
                     best_t = t; best_u = u; best_v = v; best_rank = rank; best_prim = __float_as_int(b.w);
+                    if (TWO_LEVEL) best_inst = cur_inst;
                 }
                 if (remaining == 0u) { ref = 0xffffffffu; break; }
                 ref = ((first + 1u) << 2) | (remaining - 1u);
@@ -274,11 +313,13 @@ __global__ __launch_bounds__(kExtendThreads, 4) void ptr_wf_extend(FlatView fv, 
                 sp--;
                 cur = stack_pop(my_lds, my_spill, sp);
             }
+            }
         }
 
         // finished rays publish their hit and free the lane
         if (slot != kInvalidPixel && cur == kTraversalDone) {
             w.hits[slot] = make_float4(best_t, best_u, best_v, __int_as_float(best_prim));
+            if (TWO_LEVEL) w.hit_instance[slot] = best_inst;
             slot = kInvalidPixel;
         }
     }
@@ -330,11 +371,13 @@ __global__ __launch_bounds__(kShadeThreads) void ptr_wf_shade(SceneView sv, Wave
         seed = __float_as_uint(rd.w);
         const float4 h4 = w.hits[i];
         Hit h; h.t = h4.x; h.u = h4.y; h.v = h4.z; h.prim = __float_as_int(h4.w);
+        if (sv.instance_records && h.prim >= 0) h.inst = w.hit_instance[i];
         if (STATS && h.prim >= 0) shaded = 1;
         if (sv.capture && bounce < 2u) {
             Capture* c = &sv.capture[pixel];
-            if (bounce == 0u) { c->prim0 = h.prim; c->t0 = h.prim >= 0 ? h.t : 0.0f; }
-            else { c->prim1 = h.prim; c->t1 = h.prim >= 0 ? h.t : 0.0f; }
+            const int32_t named = h.prim >= 0 && h.inst >= 0 ? (int32_t)((uint32_t)h.inst * sv.object_triangles + (uint32_t)h.prim) : h.prim;
+            if (bounce == 0u) { c->prim0 = named; c->t0 = h.prim >= 0 ? h.t : 0.0f; }
+            else { c->prim1 = named; c->t1 = h.prim >= 0 ? h.t : 0.0f; }
         }
         go_on = shade_bounce(sv, bounce, min_bounce, h, r, throughput, seed, result);
         if (go_on && bounce + 1u >= max_bounce) { go_on = false; result = mk3(0.0f, 0.0f, 0.0f); }  // loop exhausted: radiance
@@ -400,22 +443,25 @@ hipError_t launch_wf_generate(hipStream_t s, const SceneView& sv, const Wavefron
     return hipGetLastError();
 }
 
-template <bool STATS, int LEAF_WEIGHT, bool LEAF_ALL, int INNER_REPS>
+template <bool STATS, int LEAF_WEIGHT, bool LEAF_ALL, int INNER_REPS, bool TWO_LEVEL = false>
 static void launch_extend_variant(hipStream_t s, const FlatView& fv, const WavefrontScratch& w, uint32_t bounce, unsigned long long* stats,
                                   int refill) {
     const uint32_t slot_b = bounce % kMaxBounceSlots;
     const dim3 grid(w.extend_blocks), block(kExtendThreads);
     switch (refill) {
-    case 8: hipLaunchKernelGGL((ptr_wf_extend<STATS, 8, LEAF_WEIGHT, LEAF_ALL, INNER_REPS>), grid, block, 0, s, fv, w, bounce & 1u, slot_b, stats); break;
-    case 16: hipLaunchKernelGGL((ptr_wf_extend<STATS, 16, LEAF_WEIGHT, LEAF_ALL, INNER_REPS>), grid, block, 0, s, fv, w, bounce & 1u, slot_b, stats); break;
-    case 32: hipLaunchKernelGGL((ptr_wf_extend<STATS, 32, LEAF_WEIGHT, LEAF_ALL, INNER_REPS>), grid, block, 0, s, fv, w, bounce & 1u, slot_b, stats); break;
-    default: hipLaunchKernelGGL((ptr_wf_extend<STATS, 64, LEAF_WEIGHT, LEAF_ALL, INNER_REPS>), grid, block, 0, s, fv, w, bounce & 1u, slot_b, stats); break;
+    case 8: hipLaunchKernelGGL((ptr_wf_extend<STATS, 8, LEAF_WEIGHT, LEAF_ALL, INNER_REPS, TWO_LEVEL>), grid, block, 0, s, fv, w, bounce & 1u, slot_b, stats); break;
+    case 16: hipLaunchKernelGGL((ptr_wf_extend<STATS, 16, LEAF_WEIGHT, LEAF_ALL, INNER_REPS, TWO_LEVEL>), grid, block, 0, s, fv, w, bounce & 1u, slot_b, stats); break;
+    case 32: hipLaunchKernelGGL((ptr_wf_extend<STATS, 32, LEAF_WEIGHT, LEAF_ALL, INNER_REPS, TWO_LEVEL>), grid, block, 0, s, fv, w, bounce & 1u, slot_b, stats); break;
+    default: hipLaunchKernelGGL((ptr_wf_extend<STATS, 64, LEAF_WEIGHT, LEAF_ALL, INNER_REPS, TWO_LEVEL>), grid, block, 0, s, fv, w, bounce & 1u, slot_b, stats); break;
     }
 }
 
 hipError_t launch_wf_extend(hipStream_t s, const FlatView& fv, const WavefrontScratch& w, uint32_t bounce, unsigned long long* stats,
                             int refill, int leaf_weight, int leaf_all, int inner_reps) {
-    if (stats) {  // the counting variant follows inner_reps so that its step counts describe the timed configuration
+    if (fv.top.nodes) {  // placed copies: one configuration, the default one
+        if (stats) launch_extend_variant<true, 2, true, 3, true>(s, fv, w, bounce, stats, refill);
+        else launch_extend_variant<false, 2, true, 3, true>(s, fv, w, bounce, stats, refill);
+    } else if (stats) {  // the counting variant follows inner_reps so that its step counts describe the timed configuration
         if (inner_reps >= 3) launch_extend_variant<true, 2, true, 3>(s, fv, w, bounce, stats, refill);
         else launch_extend_variant<true, 2, true, 1>(s, fv, w, bounce, stats, refill);
     } else if (!leaf_all) {

@@ -59,6 +59,7 @@ def lib():
         "ptr_sampler_index": [vp, u32, P(u32)],
         "ptr_image_address": [vp, u32, P(u64)],
         "ptr_bvh_bind_flat": [vp, u32, u32],
+        "ptr_bvh_bind_instances": [vp, u32, u32],
         "ptr_dispatch": [vp, C.c_char_p, vp, u32, u32, u32],
         "ptr_set_partition": [vp, u32, u32, u32],
         "ptr_set_sample_partition": [vp, u32, u32],
@@ -85,7 +86,7 @@ def lib():
 ABI_SYMBOLS = ["ptr_ctx_create", "ptr_ctx_destroy", "ptr_ctx_set_stream", "ptr_last_error", "ptr_sync", "ptr_buffer_create",
                "ptr_buffer_destroy", "ptr_buffer_write", "ptr_buffer_read", "ptr_buffer_address", "ptr_sampler_create",
                "ptr_image_create", "ptr_image_wrap", "ptr_image_destroy", "ptr_image_upload", "ptr_image_read",
-               "ptr_image_index", "ptr_sampler_index", "ptr_image_address", "ptr_bvh_bind_flat", "ptr_dispatch",
+               "ptr_image_index", "ptr_sampler_index", "ptr_image_address", "ptr_bvh_bind_flat", "ptr_bvh_bind_instances", "ptr_dispatch",
                "ptr_set_partition", "ptr_set_sample_partition", "ptr_set_option", "ptr_set_capture", "ptr_stats_enable", "ptr_stats_read", "ptr_profile_enable",
                "ptr_profile_read", "ptr_profile_names", "ptr_device_function", "ptr_bvh_build_flat"]
 
@@ -192,6 +193,10 @@ class Context:
 
     def bind_flat(self, node_buffer, flat_buffer):
         self._check(self._L.ptr_bvh_bind_flat(self.handle, node_buffer.handle, flat_buffer.handle if flat_buffer is not None else 0))
+
+    def bind_instances(self, flat_buffer, instance_buffer):
+        """Top level over placed copies of the layout in flat_buffer (host.bvh_flatten_instances); None removes it."""
+        self._check(self._L.ptr_bvh_bind_instances(self.handle, flat_buffer.handle, instance_buffer.handle if instance_buffer is not None else 0))
 
     def dispatch(self, kernel, constants, gx, gy, gz=1):
         k = np.ascontiguousarray(constants, dtype=np.uint8)
@@ -358,6 +363,10 @@ class GpuScene:
         if flat is not None:
             self.flat_buffer = upload(flat)
             ctx.bind_flat(self.bvh_buffer, self.flat_buffer)
+        self.instance_buffer = None
+        if flat is not None and arrays.get("flat_instances") is not None:
+            self.instance_buffer = upload(arrays["flat_instances"])
+            ctx.bind_instances(self.flat_buffer, self.instance_buffer)
         self.meta = None
         if meta is not None:
             self.set_meta(meta)
