@@ -39,11 +39,19 @@ def build_scene(args, rank):
         # The reference's single-threaded builder and its 2N-1 node array (minutes, 13 GB at 10^8 triangles) are skipped:
         # the wavefront path never reads the threaded tree; a one-leaf placeholder stands in for the node buffer.
         nx, nz = (int(v) for v in args.instances.lower().split("x"))
-        sc = scenes.instance_grid(sc, nx, nz)
+        two_level = bool(getattr(args, "two_level", False))
+        if two_level:
+            # the same copies as placements of ONE object: its tree, and a top level over the copies' boxes
+            sc = dict(sc, instance_transforms=scenes.grid_transforms(sc, nx, nz), copies=nx * nz,
+                      kind=f"{sc.get('kind', 'scene')} x{nx * nz} (two-level)")
+        else:
+            sc = scenes.instance_grid(sc, nx, nz)
         t1 = time.time()
         nodes = np.zeros((1, 8), np.uint32)
         nodes[0, 3] = 0xFFFFFFFF
         flat = None if getattr(args, "bvh", "host") == "gpu" else host.bvh_flatten(sc["triangles"], None, threads=min(16, os.cpu_count() or 1))
+        if two_level and flat is not None:
+            sc["flat_instances"] = host.bvh_flatten_instances(flat, sc["instance_transforms"])
         t3 = time.time()
         c = sc["camera"]
         cam = host.camera(c["pos"], c["target"], c["v_fov"], args.width / args.height, c["aperture"], c["focus"])
@@ -160,6 +168,7 @@ def main():
     ap.add_argument("--bounces", type=int, default=4)
     ap.add_argument("--texture-size", type=int, default=512)
     ap.add_argument("--instances", default="1x1", help="NXxNZ translated copies of the scene on a grid (e.g. 6x6 of the default scene = 10^8 triangles)")
+    ap.add_argument("--two-level", action="store_true", help="with --instances: keep ONE copy of the scene and its tree, and place it through a top-level tree")
     ap.add_argument("--pipeline", default="compute", choices=["compute", "compute.megakernel", "compute.wavefront"])
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline leg (0 = skip)")
     ap.add_argument("--bvh", default="host", choices=["host", "gpu"], help="host: binned-SAH flattener (default); gpu: ptr_bvh_build_flat")
@@ -202,7 +211,7 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=world)
 
     from path_tracer_amd import distributed as ptdist
-    from path_tracer_amd import hip
+    from path_tracer_amd import hip, host
 
     sc, nodes, flat, meta, build_times = build_scene(args, rank)
 
@@ -219,6 +228,11 @@ def main():
             ctx.profile_enable(False)
             build_times["gpu_build_device_ms"] = ctx.profile_read(reset=True).get("bvh.build_flat", dict(total_ms=0.0))["total_ms"]
             ctx.bind_flat(gpu.bvh_buffer, gpu_flat)
+            if sc.get("instance_transforms") is not None:   # the top level needs the object's header only: bounds, root, stack need
+                sc["flat_instances"] = host.bvh_flatten_instances(gpu_flat.read(np.uint8, 0, 64), sc["instance_transforms"])
+                gpu.instance_buffer = ctx.create_buffer(sc["flat_instances"].nbytes)
+                gpu.instance_buffer.write(sc["flat_instances"])
+                ctx.bind_instances(gpu_flat, gpu.instance_buffer)
             flat = gpu_flat.read(np.uint8) if args.cpu_seconds > 0 else flat
             log(rank, f"GPU BVH build: {build_times['gpu_build_device_ms']:.1f} ms on the device, {build_times['gpu_build_wall_s'] * 1e3:.1f} ms wall")
         W, H = args.width, args.height
@@ -317,7 +331,7 @@ def main():
             node_bytes, tri_bytes = (64, 64) if wavefront else (32, 48)
             algo_bytes = node_bytes * stats["nodes"] + tri_bytes * stats["triangles"]  # this rank's launches
             achieved = algo_bytes / (k["total_ms"] * 1e-3) / 1e9 if k["total_ms"] > 0 else 0.0
-            line_workload = (f"{sc['kind']} (Bistro-Exterior-class procedural stand-in), {sc['triangles'].shape[0]} triangles, "
+            line_workload = (f"{sc['kind']} (Bistro-Exterior-class procedural stand-in), {sc['triangles'].shape[0] * int(sc.get('copies', 1))} triangles, "
                              f"{W}x{H}, 1 spp per step, max_bounce {args.bounces}, min_bounce 1, dof off")
             ks = solo.get(dominant, dict(launches=0, total_ms=0.0))
             solo_bytes = algo_bytes * ks["launches"] / max(1, k["launches"])
@@ -329,6 +343,7 @@ def main():
                 "config": {"workload": line_workload,
                            "pipeline": "wavefront over flattened BVH" if wavefront else "megakernel over threaded BVH",
                            "partition": "samples" if world > 1 else "none", "frames_in_flight": args.frames_in_flight, "bvh_builder": args.bvh,
+                           "instancing": "none" if args.instances in ("", "1x1") else (f"{args.instances} copies through a top-level tree" if args.two_level else f"{args.instances} copies written out"),
                            "rays_per_step_per_gpu": stats["rays"] / args.steps},
                 "ms_per_frame": elapsed / args.steps * 1e3,
                 "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
