@@ -2,7 +2,7 @@
 // Builds the scene, wires the compute render pass exactly as src/main.cpp:261-270 does, renders `spp`
 // frames with the per-frame protocol of src/main.cpp:406-416 and writes the accumulated image.
 //
-//   ptr_headless --scene file.{ptrscene,gltf,glb} [--apply-transforms] [--gpu-bvh] --width W --height H --spp N [--max-bounce B] [--min-bounce B]
+//   ptr_headless --scene file.{ptrscene,gltf,glb} [--apply-transforms] [--gpu-bvh] [--copies NX NZ] --width W --height H --spp N [--max-bounce B] [--min-bounce B]
 //                [--dof 0|1] [--downscale D] [--debug-bvh 0|1] [--pipeline compute|compute.megakernel|compute.wavefront]
 //                [--pos x y z] [--target x y z] [--fov deg] [--aperture a] [--focus f] [--out image.pfm|image.ppm|image.png]
 #include <chrono>
@@ -57,6 +57,7 @@ scene_source load_source(const std::string& path, bool apply_transforms) {
 int main(int argc, char** argv) {
     std::string scene_path, out_path, pipeline = "compute";
     bool apply_transforms = false, gpu_bvh = false;
+    uint32_t copies_x = 1, copies_z = 1;
     uint32_t width = 400, height = 225, spp = 1, max_bounce = 3, min_bounce = 1, dof = 0, debug_bvh = 0;
     int32_t downscale = 1;
     float pos[3] = { 13.f, 2.f, -3.f }, target[3] = { 0.f, 0.f, 0.f }, v_fov = 90.f, aperture = 0.1f, focus = 10.f;  // src/main.cpp:219-223
@@ -66,6 +67,7 @@ int main(int argc, char** argv) {
         if (is("--scene")) scene_path = next();
         else if (is("--apply-transforms")) apply_transforms = true;
         else if (is("--gpu-bvh")) gpu_bvh = true;
+        else if (is("--copies")) { copies_x = (uint32_t)std::atoi(next()); copies_z = (uint32_t)std::atoi(next()); }
         else if (is("--out")) out_path = next();
         else if (is("--pipeline")) pipeline = next();
         else if (is("--width")) width = (uint32_t)std::atoi(next());
@@ -93,6 +95,7 @@ int main(int argc, char** argv) {
                          load_source(scene_path, apply_transforms), pipeline != "compute.megakernel", gpu_bvh);
         main_scene.meta.max_bounce = max_bounce; main_scene.meta.min_bounce = min_bounce;
         main_scene.meta.enable_dof = dof; main_scene.meta.debug_bvh = debug_bvh; main_scene.meta.downscale_factor = downscale;
+        if (copies_x * copies_z > 1) main_scene.place_copies_on_grid(copies_x, copies_z);  // the scene repeated on a grid, through a top-level tree
         const double build_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_build).count();
 
         ComputeRenderpass* raytracing_pass = renderer.create_compute_renderpass();
@@ -121,8 +124,8 @@ int main(int argc, char** argv) {
         }
         renderer.wait_idle();
         const double render_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-        std::fprintf(stderr, "ptr_headless: %zu triangles (%s BVH), scene build %.2f s, %u frames %ux%u in %.3f s (%.3f ms/frame)\n",
-                     main_scene.triangle_count, main_scene.bvh_mode.c_str(), build_s, spp, width, height, render_s, render_s * 1e3 / (spp ? spp : 1));
+        std::fprintf(stderr, "ptr_headless: %zu triangles x %zu (%s BVH), scene build %.2f s, %u frames %ux%u in %.3f s (%.3f ms/frame)\n",
+                     main_scene.triangle_count, main_scene.copy_count, main_scene.bvh_mode.c_str(), build_s, spp, width, height, render_s, render_s * 1e3 / (spp ? spp : 1));
 
         if (!out_path.empty()) {
             std::vector<float> rgba((size_t)width * height * 4);

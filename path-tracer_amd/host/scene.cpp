@@ -103,10 +103,46 @@ scene::scene(const camera& cam, uint32_t width, uint32_t height, const scene_sou
     }
 }
 
+void scene::place_copies(const std::vector<float>& object_to_world) {
+    if (!flat_bvh_buffer) throw std::runtime_error("scene: placed copies need the flattened layout");
+    if (instances_buffer) {
+        hiprenderer::check(ptr_bvh_bind_instances(hiprenderer::api, flat_bvh_buffer->device_buffer, 0), "ptr_bvh_bind_instances");
+        delete instances_buffer;
+        instances_buffer = nullptr;
+        copy_count = 1;
+    }
+    if (object_to_world.empty()) return;
+    // the top level needs the object's header only: its bounds, root and stack need
+    std::vector<uint8_t> header(sizeof(flat_bvh_header));
+    flat_bvh_buffer->read(header.data(), 0, header.size());
+    const std::vector<uint8_t> top = bvh::flatten_instances(header, object_to_world);
+    instances_buffer = hiprenderer::create_buffer(top.size());
+    instances_buffer->write(top.data(), 0, top.size());
+    hiprenderer::check(ptr_bvh_bind_instances(hiprenderer::api, flat_bvh_buffer->device_buffer, instances_buffer->device_buffer), "ptr_bvh_bind_instances");
+    copy_count = object_to_world.size() / 12;
+}
+
+void scene::place_copies_on_grid(uint32_t nx, uint32_t nz) {
+    if (!flat_bvh_buffer) throw std::runtime_error("scene: placed copies need the flattened layout");
+    if (nx == 0 || nz == 0) throw std::runtime_error("scene: the grid needs at least one copy each way");
+    flat_bvh_header header;
+    flat_bvh_buffer->read(&header, 0, sizeof header);
+    const float step_x = (header.scene_max[0] - header.scene_min[0]) * 1.02f, step_z = (header.scene_max[2] - header.scene_min[2]) * 1.02f;
+    std::vector<float> m;
+    m.reserve((size_t)nx * nz * 12);
+    for (uint32_t ix = 0; ix < nx; ix++)
+        for (uint32_t iz = 0; iz < nz; iz++) {
+            const float tx = ((float)ix - (float)(nx - 1) / 2.f) * step_x, tz = ((float)iz - (float)(nz - 1) / 2.f) * step_z;
+            const float rows[12] = { 1.f, 0.f, 0.f, tx, 0.f, 1.f, 0.f, 0.f, 0.f, 0.f, 1.f, tz };
+            m.insert(m.end(), rows, rows + 12);
+        }
+    place_copies(m);
+}
+
 void scene::upload_metadata() const { scene_buffer->write(&meta, 0, sizeof(meta)); }
 
 scene::~scene() {
-    for (Buffer* b : { scene_buffer, indices_buffer, positions_buffer, normals_buffer, uvs_buffer, bvh_buffer, materials_buffer, flat_bvh_buffer }) delete b;
+    for (Buffer* b : { scene_buffer, indices_buffer, positions_buffer, normals_buffer, uvs_buffer, bvh_buffer, materials_buffer, flat_bvh_buffer, instances_buffer }) delete b;
     for (Texture* t : textures) delete t;
     delete sampler;
 }

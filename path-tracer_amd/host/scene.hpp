@@ -43,6 +43,13 @@ public:
     scene(const camera& cam, uint32_t width, uint32_t height, const scene_source& source, bool flatten_bvh = true, bool gpu_bvh = false);
     ~scene();
 
+    // Instancing (an extension; the reference writes repeated objects out copy by copy): renders `object_to_world.size() / 12`
+    // placed copies of this scene instead of the scene itself.  Each transform is the three rows (3x3 part, translation)
+    // of an invertible affine matrix.  Needs the flattened layout; an empty vector goes back to the single object.
+    void place_copies(const std::vector<float>& object_to_world);
+    // nx * nz translated copies on a grid in x and z, 2 % of the scene's extent apart.
+    void place_copies_on_grid(uint32_t nx, uint32_t nz);
+
     // Writes `meta` where the kernels read it (slot 0 of the scene buffer).
     void upload_metadata() const;
 
@@ -56,6 +63,8 @@ public:
     Buffer* bvh_buffer = nullptr;
     Buffer* materials_buffer = nullptr;
     Buffer* flat_bvh_buffer = nullptr;  // the flattened layout bound to bvh_buffer (wavefront path), may be null
+    Buffer* instances_buffer = nullptr; // the top level over placed copies bound to flat_bvh_buffer, may be null
+    size_t copy_count = 1;
 
     size_t triangle_count = 0;
     std::string bvh_mode;               // "reference_order" or "sah_partitioned"

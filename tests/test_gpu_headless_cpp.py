@@ -111,3 +111,38 @@ def test_headless_driver_gpu_built_bvh(tmp_path):
 def test_headless_reports_errors():
     r = subprocess.run([HEADLESS, "--scene", "/nonexistent.ptrscene"], capture_output=True, text=True, timeout=60)
     assert r.returncode == 1 and "cannot open" in r.stderr
+
+
+def test_headless_driver_places_copies_on_a_grid(tmp_path):
+    """--copies NX NZ: scene::place_copies_on_grid -> bvh::flatten_instances -> ptr_bvh_bind_instances; the image equals the
+    oracle's two-level traversal over the same placements."""
+    from path_tracer_amd import host
+    W, H, SPP, NX, NZ = 96, 54, 2, 3, 2
+    b = make_bundle("atrium", 3000, W, H, max_bounce=4)
+    scene_file = str(tmp_path / "scene.ptrscene")
+    out_file = str(tmp_path / "out.pfm")
+    scenes.save_ptrscene(b, scene_file)
+    h = host.flat_header(b["flat"])
+    step_x = np.float32(h["scene_max"][0] - h["scene_min"][0]) * np.float32(1.02)
+    step_z = np.float32(h["scene_max"][2] - h["scene_min"][2]) * np.float32(1.02)
+    m = np.zeros((NX * NZ, 3, 4), np.float32)
+    m[:, 0, 0] = m[:, 1, 1] = m[:, 2, 2] = 1.0
+    for ix in range(NX):
+        for iz in range(NZ):
+            m[ix * NZ + iz, 0, 3] = (np.float32(ix) - np.float32(NX - 1) / np.float32(2)) * step_x
+            m[ix * NZ + iz, 2, 3] = (np.float32(iz) - np.float32(NZ - 1) / np.float32(2)) * step_z
+    size = float(max(step_x * NX, step_z * NZ))
+    pos, target = [0.3 * size, 0.6 * size, -0.8 * size], [0.0, 0.0, 0.0]
+    cmd = [HEADLESS, "--scene", scene_file, "--copies", str(NX), str(NZ), "--width", str(W), "--height", str(H), "--spp", str(SPP),
+           "--max-bounce", "4", "--out", out_file, "--pos", *map(str, pos), "--target", *map(str, target), "--fov", "60", "--aperture", "0",
+           "--focus", "10"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    assert f"x {NX * NZ}" in r.stderr
+    cam = host.camera(pos, target, 60.0, W / H, 0.0, 10.0)
+    two = dict(b, flat_instances=host.bvh_flatten_instances(b["flat"], m), meta=scenes.pack_metadata(cam, W, H, max_bounce=4))
+    ref, _, aov = oracle_frames(two, SPP, use_flat=True, aov=True)
+    hit = aov[0][..., 0]
+    assert len(np.unique(hit[hit >= 0] // b["triangles"].shape[0])) == NX * NZ, "every copy is in view"
+    img = read_ptrf(out_file)
+    assert np.array_equal(img, ref), f"{int((np.abs(img - ref).max(axis=2) > 0).sum())} pixels differ\n{r.stderr}"
