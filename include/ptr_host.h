@@ -37,6 +37,15 @@ int32_t ptrh_bvh_flatten(const float* positions, int64_t n, const int32_t* ranks
  * records (world-to-object rows, object root) in a malloc'ed blob for ptr_bvh_bind_instances; free with ptrh_free. */
 int32_t ptrh_bvh_flatten_instances(const void* object_blob, uint64_t object_bytes, const float* object_to_world, int64_t instance_count,
                                    uint32_t threads, void** blob_out, uint64_t* size_out);
+/* bvh::flatten_objects(): several objects in ONE flattened layout -- triangles [object_first[k], object_first[k+1]) form
+ * object k (object_first holds object_count + 1 offsets, from 0 to n), each with a tree of its own; primitive ids stay
+ * global.  objects_out receives object_count entries of 8 words: root reference (int32), stack need (uint32), box min
+ * (3 floats), box max (3 floats).  The header names object 0's root. */
+int32_t ptrh_bvh_flatten_objects(const float* positions, int64_t n, const int32_t* ranks, const uint32_t* object_first, int64_t object_count,
+                                 uint32_t threads, void** blob_out, uint64_t* size_out, void* objects_out);
+/* bvh::flatten_instances() over such objects: copy i shows objects[object_of_copy[i]] through object_to_world[12 i ..]. */
+int32_t ptrh_bvh_flatten_placements(const void* objects, int64_t object_count, const uint32_t* object_of_copy, const float* object_to_world,
+                                    int64_t copy_count, uint32_t threads, void** blob_out, uint64_t* size_out);
 void ptrh_free(void* p);
 
 /* camera::camera + optional set_aspect_ratio / move / rotate_y -- reference: src/camera.cpp:6-57.

@@ -655,30 +655,111 @@ bool invert_affine(const float* m, double inv[12]) {
 }
 }  // namespace
 
+std::vector<uint8_t> bvh::flatten_objects(const std::vector<triangle>& tris, const std::vector<int32_t>& ranks, const std::vector<uint32_t>& object_first,
+                                          std::vector<flat_bvh_object>& objects, unsigned threads) {
+    if (object_first.size() < 2 || object_first.front() != 0 || object_first.back() != tris.size()) throw bvh_build_error("flatten_objects: the offsets must run from 0 to the triangle count");
+    if (tris.size() >= (1u << 28)) throw bvh_build_error("flatten_objects: too many triangles to be instanced");
+    if (!ranks.empty() && ranks.size() != tris.size()) throw bvh_build_error("flatten_objects: ranks/triangles size mismatch");
+    const size_t count = object_first.size() - 1;
+    objects.assign(count, flat_bvh_object{});
+    std::vector<flat_bvh_node> all_nodes;
+    std::vector<flat_bvh_triangle> all_tris;
+    all_tris.reserve(tris.size());
+    aabb whole;
+    uint32_t deepest = 0;
+    for (size_t k = 0; k < count; k++) {
+        const uint32_t first = object_first[k], last = object_first[k + 1];
+        if (last <= first) throw bvh_build_error("flatten_objects: an object without triangles");
+        const std::vector<triangle> part(tris.begin() + first, tris.begin() + last);
+        std::vector<int32_t> part_ranks;
+        if (!ranks.empty()) part_ranks.assign(ranks.begin() + first, ranks.begin() + last);
+        const std::vector<uint8_t> blob = flatten(part, part_ranks, threads);
+        const auto* h = reinterpret_cast<const flat_bvh_header*>(blob.data());
+        const auto* nodes = reinterpret_cast<const flat_bvh_node*>(blob.data() + h->nodes_offset);
+        const auto* records = reinterpret_cast<const flat_bvh_triangle*>(blob.data() + h->triangles_offset);
+        const int32_t node_base = (int32_t)all_nodes.size();
+        const uint32_t tri_base = (uint32_t)all_tris.size();
+        // references move with the arrays: inner indices by the nodes before, leaf references by the triangles before
+        auto moved = [&](int32_t ref) -> int32_t {
+            if (ref == FLAT_BVH_EMPTY_CHILD) return ref;
+            if (ref >= 0) return ref + node_base;
+            const uint32_t r = (uint32_t)~ref;
+            return ~(int32_t)((((r >> 2) + tri_base) << 2) | (r & 3u));
+        };
+        for (uint32_t i = 0; i < h->node_count; i++) {
+            flat_bvh_node nd = nodes[i];
+            for (int32_t& c : nd.child) c = moved(c);
+            all_nodes.push_back(nd);
+        }
+        for (uint32_t i = 0; i < h->triangle_count; i++) {
+            flat_bvh_triangle t = records[i];
+            t.primitive_id += (int32_t)first;                       // global primitive ids
+            if (ranks.empty()) t.rank += (int32_t)first;            // rank = primitive index
+            all_tris.push_back(t);
+        }
+        flat_bvh_object& o = objects[k];
+        o.root = moved(h->root);
+        o.max_depth = h->max_depth;
+        for (int a = 0; a < 3; a++) { o.box_min[a] = h->scene_min[a]; o.box_max[a] = h->scene_max[a]; }
+        whole.union_with(aabb(vec3(h->scene_min[0], h->scene_min[1], h->scene_min[2]), vec3(h->scene_max[0], h->scene_max[1], h->scene_max[2])));
+        deepest = std::max(deepest, h->max_depth);
+    }
+    const size_t nodes_bytes = all_nodes.size() * sizeof(flat_bvh_node);
+    std::vector<uint8_t> blob(sizeof(flat_bvh_header) + nodes_bytes + all_tris.size() * sizeof(flat_bvh_triangle), 0);
+    auto* header = reinterpret_cast<flat_bvh_header*>(blob.data());
+    if (!all_nodes.empty()) std::memcpy(blob.data() + sizeof(flat_bvh_header), all_nodes.data(), nodes_bytes);
+    std::memcpy(blob.data() + sizeof(flat_bvh_header) + nodes_bytes, all_tris.data(), all_tris.size() * sizeof(flat_bvh_triangle));
+    header->magic = FLAT_BVH_MAGIC;
+    header->version = FLAT_BVH_VERSION;
+    header->node_count = (uint32_t)all_nodes.size();
+    header->triangle_count = (uint32_t)all_tris.size();
+    header->nodes_offset = sizeof(flat_bvh_header);
+    header->triangles_offset = sizeof(flat_bvh_header) + nodes_bytes;
+    header->root = objects[0].root;
+    header->max_depth = deepest;
+    for (int a = 0; a < 3; a++) { header->scene_min[a] = whole.minimum.v[a]; header->scene_max[a] = whole.maximum.v[a]; }
+    return blob;
+}
+
 std::vector<uint8_t> bvh::flatten_instances(const std::vector<uint8_t>& object_blob, const std::vector<float>& object_to_world, unsigned threads) {
     if (object_blob.size() < sizeof(flat_bvh_header)) throw bvh_build_error("flatten_instances: no object tree");
     const auto* object_header = reinterpret_cast<const flat_bvh_header*>(object_blob.data());
     if (object_header->magic != FLAT_BVH_MAGIC || object_header->version != FLAT_BVH_VERSION) throw bvh_build_error("flatten_instances: not a flattened tree");
+    if (object_header->triangle_count >= (1u << 28)) throw bvh_build_error("flatten_instances: object tree too large to be instanced");
+    flat_bvh_object whole;
+    whole.root = object_header->root;
+    whole.max_depth = object_header->max_depth;
+    for (int a = 0; a < 3; a++) { whole.box_min[a] = object_header->scene_min[a]; whole.box_max[a] = object_header->scene_max[a]; }
+    return flatten_instances(std::vector<flat_bvh_object>{ whole }, std::vector<uint32_t>(object_to_world.size() / 12, 0u), object_to_world, threads);
+}
+
+std::vector<uint8_t> bvh::flatten_instances(const std::vector<flat_bvh_object>& objects, const std::vector<uint32_t>& object_of_copy,
+                                            const std::vector<float>& object_to_world, unsigned threads) {
+    if (objects.empty()) throw bvh_build_error("flatten_instances: no object");
     if (object_to_world.empty() || object_to_world.size() % 12 != 0) throw bvh_build_error("flatten_instances: transforms are 12 floats each");
     const size_t count = object_to_world.size() / 12;
+    if (object_of_copy.size() != count) throw bvh_build_error("flatten_instances: one object index per transform");
     if (count >= FLAT_INSTANCE_LIMIT) throw bvh_build_error("flatten_instances: too many instances for the leaf reference encoding");
-    if (object_header->triangle_count >= (1u << 28)) throw bvh_build_error("flatten_instances: object tree too large to be instanced");
 
     // World box of each instance: the eight corners of the object's box through the matrix (double), rounded
     // outwards and padded by 2^-18 of the box's size and distance from the origin -- room for the rounding of the
     // object-space ray (a few 2^-24 of the same magnitudes) that the traversal below the instance sees.
     std::vector<flat_bvh_instance> records(count);
     std::vector<triangle> proxies(count);  // a "triangle" spanning the box: same bounds, centroid near the middle
+    uint32_t object_depth = 0;
     for (size_t k = 0; k < count; k++) {
+        if (object_of_copy[k] >= objects.size()) throw bvh_build_error("flatten_instances: a copy names an object that does not exist");
+        const flat_bvh_object& object = objects[object_of_copy[k]];
+        object_depth = std::max(object_depth, object.max_depth);
         const float* m = &object_to_world[k * 12];
         for (int j = 0; j < 12; j++) if (!std::isfinite(m[j])) throw bvh_build_error("flatten_instances: non-finite transform");
         double inv[12];
         if (!invert_affine(m, inv)) throw bvh_build_error("flatten_instances: singular transform");
         double lo[3] = { 1e300, 1e300, 1e300 }, hi[3] = { -1e300, -1e300, -1e300 };
         for (int corner = 0; corner < 8; corner++) {
-            const double p[3] = { (corner & 1) ? object_header->scene_max[0] : object_header->scene_min[0],
-                                  (corner & 2) ? object_header->scene_max[1] : object_header->scene_min[1],
-                                  (corner & 4) ? object_header->scene_max[2] : object_header->scene_min[2] };
+            const double p[3] = { (corner & 1) ? object.box_max[0] : object.box_min[0],
+                                  (corner & 2) ? object.box_max[1] : object.box_min[1],
+                                  (corner & 4) ? object.box_max[2] : object.box_min[2] };
             for (int a = 0; a < 3; a++) {
                 const double w = (double)m[a * 4] * p[0] + (double)m[a * 4 + 1] * p[1] + (double)m[a * 4 + 2] * p[2] + (double)m[a * 4 + 3];
                 lo[a] = std::min(lo[a], w);
@@ -697,7 +778,7 @@ std::vector<uint8_t> bvh::flatten_instances(const std::vector<uint8_t>& object_b
         proxies[k] = triangle(bmin, bmax, (bmin + bmax) / 2.f);
         flat_bvh_instance& r = records[k];
         for (int j = 0; j < 12; j++) r.world_to_object[j] = (float)inv[j];
-        r.object_root = object_header->root;
+        r.object_root = object.root;
         r.pad[0] = r.pad[1] = r.pad[2] = 0;
     }
 
@@ -705,7 +786,7 @@ std::vector<uint8_t> bvh::flatten_instances(const std::vector<uint8_t>& object_b
     const std::vector<sah_node> nodes = build_sah(proxies, order, 1, threads);
     const wide_layout L = collapse_tree(nodes);
     // one entry marks the way back out of an instance; the object's own stack sits on top of it
-    const uint32_t stack_need = L.stack_need + 1u + object_header->max_depth;
+    const uint32_t stack_need = L.stack_need + 1u + object_depth;
     if (stack_need > FLAT_BVH_MAX_DEPTH) throw bvh_build_error("flatten_instances: the two trees need a deeper traversal stack than the kernels have");
 
     const size_t nodes_bytes = L.wide.size() * sizeof(flat_bvh_node);

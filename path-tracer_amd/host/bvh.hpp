@@ -88,6 +88,14 @@ struct flat_bvh_instance {
     int32_t pad[3];
 };
 static_assert(sizeof(flat_bvh_instance) == 64, "instance record is one 64-byte line");
+// One object inside a flattened layout that holds several (bvh::flatten_objects): where its tree starts and what it needs.
+struct flat_bvh_object {
+    int32_t root;
+    uint32_t max_depth;
+    float box_min[3];
+    float box_max[3];
+};
+static_assert(sizeof(flat_bvh_object) == 32, "object entry is eight words");
 constexpr uint32_t FLAT_INSTANCES_MAGIC = 0x49525450u;  // "PTRI"
 constexpr uint32_t FLAT_INSTANCE_TAG = 0x40000000u;      // set in ~ref of an instance leaf; triangle leaves of an instanced tree stay below it
 constexpr uint32_t FLAT_INSTANCE_LIMIT = 0x3ffffff0u;    // instance indices above are reserved for the kernels' markers
@@ -116,6 +124,16 @@ public:
     // Returns one contiguous blob: header | nodes | triangles.
     static std::vector<uint8_t> flatten(const std::vector<triangle>& triangles, const std::vector<int32_t>& ranks,
                                         unsigned threads = 0);
+
+    // Several objects in ONE layout: triangles [object_first[k], object_first[k + 1]) form object k, each with a tree of
+    // its own; node and triangle records of all objects share the blob's two arrays and primitive ids stay global, so the
+    // index / vertex / shading buffers need no per-object base.  The header names object 0's root, the union of the boxes
+    // and the deepest stack; `objects` receives one entry per object.
+    static std::vector<uint8_t> flatten_objects(const std::vector<triangle>& triangles, const std::vector<int32_t>& ranks,
+                                                const std::vector<uint32_t>& object_first, std::vector<flat_bvh_object>& objects, unsigned threads = 0);
+    // Top level over placed copies of those objects: copy i shows objects[object_of_copy[i]] through object_to_world[12 i ..].
+    static std::vector<uint8_t> flatten_instances(const std::vector<flat_bvh_object>& objects, const std::vector<uint32_t>& object_of_copy,
+                                                  const std::vector<float>& object_to_world, unsigned threads = 0);
 
     // Top level over `object_to_world.size() / 12` instances (rows of an affine object-to-world matrix each) of the
     // tree in `object_blob`.  Returns header | nodes | instance records.

@@ -105,6 +105,52 @@ int32_t ptrh_bvh_flatten_instances(const void* object_blob, uint64_t object_byte
     }
 }
 
+int32_t ptrh_bvh_flatten_objects(const float* positions, int64_t n, const int32_t* ranks, const uint32_t* object_first, int64_t object_count,
+                                 uint32_t threads, void** blob_out, uint64_t* size_out, void* objects_out) {
+    try {
+        if (!positions || !object_first || !blob_out || !size_out || !objects_out) { g_last_error = "ptrh_bvh_flatten_objects: null argument"; return -1; }
+        if (n <= 0 || object_count <= 0) { g_last_error = "ptrh_bvh_flatten_objects: counts must be positive"; return -1; }
+        const std::vector<triangle> tris = make_triangles(positions, n);
+        std::vector<int32_t> r;
+        if (ranks) r.assign(ranks, ranks + n);
+        const std::vector<uint32_t> first(object_first, object_first + object_count + 1);
+        std::vector<flat_bvh_object> objects;
+        const std::vector<uint8_t> blob = bvh::flatten_objects(tris, r, first, objects, threads);
+        void* mem = std::malloc(blob.size());
+        if (!mem) { g_last_error = "ptrh_bvh_flatten_objects: out of memory"; return -1; }
+        std::memcpy(mem, blob.data(), blob.size());
+        std::memcpy(objects_out, objects.data(), objects.size() * sizeof(flat_bvh_object));
+        *blob_out = mem;
+        *size_out = blob.size();
+        return 0;
+    } catch (const std::exception& e) {
+        g_last_error = e.what();
+        return -1;
+    }
+}
+
+int32_t ptrh_bvh_flatten_placements(const void* objects, int64_t object_count, const uint32_t* object_of_copy, const float* object_to_world,
+                                    int64_t copy_count, uint32_t threads, void** blob_out, uint64_t* size_out) {
+    try {
+        if (!objects || !object_of_copy || !object_to_world || !blob_out || !size_out) { g_last_error = "ptrh_bvh_flatten_placements: null argument"; return -1; }
+        if (object_count <= 0 || copy_count <= 0) { g_last_error = "ptrh_bvh_flatten_placements: counts must be positive"; return -1; }
+        std::vector<flat_bvh_object> table((size_t)object_count);
+        std::memcpy(table.data(), objects, table.size() * sizeof(flat_bvh_object));
+        const std::vector<uint32_t> which(object_of_copy, object_of_copy + copy_count);
+        const std::vector<float> transforms(object_to_world, object_to_world + copy_count * 12);
+        const std::vector<uint8_t> blob = bvh::flatten_instances(table, which, transforms, threads);
+        void* mem = std::malloc(blob.size());
+        if (!mem) { g_last_error = "ptrh_bvh_flatten_placements: out of memory"; return -1; }
+        std::memcpy(mem, blob.data(), blob.size());
+        *blob_out = mem;
+        *size_out = blob.size();
+        return 0;
+    } catch (const std::exception& e) {
+        g_last_error = e.what();
+        return -1;
+    }
+}
+
 void ptrh_free(void* p) { std::free(p); }
 
 void ptrh_camera(const float pos[3], const float target[3], float v_fov, float aspect, float aperture, float focus_dist,

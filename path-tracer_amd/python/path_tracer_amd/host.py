@@ -22,6 +22,12 @@ def lib():
         L.ptrh_bvh_flatten_instances.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_int64, C.c_uint32, C.POINTER(C.c_void_p),
                                                  C.POINTER(C.c_uint64)]
         L.ptrh_bvh_flatten_instances.restype = C.c_int32
+        L.ptrh_bvh_flatten_objects.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_uint32, C.POINTER(C.c_void_p),
+                                               C.POINTER(C.c_uint64), C.c_void_p]
+        L.ptrh_bvh_flatten_objects.restype = C.c_int32
+        L.ptrh_bvh_flatten_placements.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_uint32, C.POINTER(C.c_void_p),
+                                                  C.POINTER(C.c_uint64)]
+        L.ptrh_bvh_flatten_placements.restype = C.c_int32
         L.ptrh_free.argtypes = [C.c_void_p]
         L.ptrh_camera.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p,
                                   C.c_int32, C.c_void_p]
@@ -101,6 +107,46 @@ def bvh_flatten_instances(object_blob, object_to_world, threads=0):
     return blob
 
 
+OBJECT_DTYPE = np.dtype([("root", np.int32), ("max_depth", np.uint32), ("box_min", np.float32, 3), ("box_max", np.float32, 3)])
+
+
+def bvh_flatten_objects(triangles, object_first, ranks=None, threads=0):
+    """Several objects in one flattened layout: triangles [object_first[k], object_first[k + 1]) form object k.
+    Returns (blob, objects): objects is an OBJECT_DTYPE array, one entry per object."""
+    tri = np.ascontiguousarray(triangles, dtype=np.float32).reshape(-1, 9)
+    first = np.ascontiguousarray(object_first, dtype=np.uint32)
+    r = None if ranks is None else np.ascontiguousarray(ranks, dtype=np.int32)
+    objects = np.zeros(max(1, first.size - 1), OBJECT_DTYPE)
+    ptr = C.c_void_p()
+    size = C.c_uint64()
+    rc = lib().ptrh_bvh_flatten_objects(tri.ctypes.data, tri.shape[0], None if r is None else r.ctypes.data, first.ctypes.data, first.size - 1,
+                                        threads, C.byref(ptr), C.byref(size), objects.ctypes.data)
+    if rc != 0:
+        raise HostError(lib().ptrh_last_error().decode())
+    try:
+        blob = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint8)), shape=(size.value,)).copy()
+    finally:
+        lib().ptrh_free(ptr)
+    return blob, objects
+
+
+def bvh_flatten_placements(objects, object_of_copy, object_to_world, threads=0):
+    """Top level over placed copies of the objects of bvh_flatten_objects: copy i shows objects[object_of_copy[i]]."""
+    table = np.ascontiguousarray(objects, dtype=OBJECT_DTYPE)
+    which = np.ascontiguousarray(object_of_copy, dtype=np.uint32)
+    m = np.ascontiguousarray(object_to_world, dtype=np.float32).reshape(-1, 12)
+    ptr = C.c_void_p()
+    size = C.c_uint64()
+    rc = lib().ptrh_bvh_flatten_placements(table.ctypes.data, table.size, which.ctypes.data, m.ctypes.data, m.shape[0], threads, C.byref(ptr), C.byref(size))
+    if rc != 0:
+        raise HostError(lib().ptrh_last_error().decode())
+    try:
+        blob = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint8)), shape=(size.value,)).copy()
+    finally:
+        lib().ptrh_free(ptr)
+    return blob
+
+
 def flat_header(blob):
     u = blob[:64].view(np.uint32)
     q = blob[:64].view(np.uint64)
@@ -122,7 +168,7 @@ def camera(pos, target, v_fov, aspect, aperture, focus, ops=()):
     return out
 
 
-HOST_SYMBOLS = ["ptrh_last_error", "ptrh_sizes", "ptrh_bvh_build", "ptrh_bvh_visit_ranks", "ptrh_bvh_flatten", "ptrh_bvh_flatten_instances", "ptrh_free", "ptrh_camera",
+HOST_SYMBOLS = ["ptrh_last_error", "ptrh_sizes", "ptrh_bvh_build", "ptrh_bvh_visit_ranks", "ptrh_bvh_flatten", "ptrh_bvh_flatten_instances", "ptrh_bvh_flatten_objects", "ptrh_bvh_flatten_placements", "ptrh_free", "ptrh_camera",
                 "ptrh_gltf_load", "ptrh_scene_load", "ptrh_scene_counts", "ptrh_scene_arrays", "ptrh_scene_texture", "ptrh_scene_free",
                 "ptrh_image_decode", "ptrh_image_encode_png", "ptrh_json_dump"]
 

@@ -381,6 +381,34 @@ def instance_grid(scene, nx, nz, spacing=None):
     return out
 
 
+def concat_scenes(parts):
+    """Several scenes as ONE set of arrays in the 4-word index layout, each part's triangles in a run of their own.
+    Returns (scene, object_first): object_first holds len(parts) + 1 triangle offsets."""
+    positions, normals, uvs, indices, materials, textures, triangles = [], [], [], [], [], [None], []
+    object_first = [0]
+    nv = nm = 0
+    for part in parts:
+        w = widen_indices(part) if int(part.get("index_words", 3)) == 3 else part
+        I = np.asarray(w["indices"], np.uint32).reshape(-1, 4).copy()
+        I[:, :3] += np.uint32(nv)
+        I[:, 3] += np.uint32(nm)
+        m = np.array(w["materials"], dtype=MATERIAL_DTYPE, copy=True)
+        shift = len(textures) - 1                                  # texture numbers are 1-based, 0 = none
+        for field in ("albedo_tex", "mr_tex"):
+            m[field] = np.where(m[field] > 0, m[field] + shift, 0)
+        textures += [t for t in w["textures"][1:]]
+        positions.append(np.asarray(w["positions"], np.float32)); normals.append(np.asarray(w["normals"], np.float32))
+        uvs.append(np.asarray(w["uvs"], np.float32)); indices.append(I.reshape(-1)); materials.append(m)
+        triangles.append(np.asarray(w["triangles"], np.float32).reshape(-1, 9))
+        nv += len(w["positions"]) // 3
+        nm += len(m)
+        object_first.append(object_first[-1] + I.shape[0])
+    out = dict(parts[0], kind="+".join(str(p.get("kind", "scene")) for p in parts), positions=np.concatenate(positions), normals=np.concatenate(normals),
+               uvs=np.concatenate(uvs), indices=np.concatenate(indices), index_words=4, materials=np.concatenate(materials), textures=textures,
+               triangles=np.concatenate(triangles))
+    return out, np.array(object_first, np.uint32)
+
+
 def grid_transforms(scene, nx, nz, spacing=None):
     """The placements of instance_grid() as (nx * nz, 3, 4) object-to-world matrices, in the same order."""
     P = np.asarray(scene["positions"], np.float32).reshape(-1, 3)

@@ -95,3 +95,15 @@ def test_bad_instance_blobs_are_refused(ctx):
     with pytest.raises(hip.HipError, match="instances"):
         attempt(bad)
     attempt(good)
+
+
+def test_copies_of_two_objects_are_bit_exact_vs_oracle(ctx):
+    """Two different objects in one layout (bvh::flatten_objects), seven copies naming them in turn."""
+    from test_two_level import two_object_bundle
+    b = two_object_bundle(112, 72, max_bounce=5)
+    img, gs, cap, st = gpu_frames(ctx, b, 3, "compute.wavefront", capture=True, stats=True)
+    ref, counters, aov = oracle_for(b, gs, 3, use_flat=True, aov=True)
+    same(cap[0], aov[0], "copy * triangles + primitive of the first two hits")
+    same(cap[1], aov[1], "hit distances of the first two hits")
+    same(img, ref, "image")
+    assert {k: st[k] for k in ("rays", "nodes", "triangles", "shaded")} == {k: counters[k] for k in ("rays", "nodes", "triangles", "shaded")}

@@ -133,3 +133,74 @@ def test_single_instance_identity_is_the_object():
     assert np.array_equal(cap1[0][..., 0], cap2[0][..., 0]) and np.array_equal(cap1[1][..., 0], cap2[1][..., 0])
     assert (cap1[0][..., 1] == cap2[0][..., 1]).mean() > 0.99
     assert np.abs(img1 - img2).mean() < 2e-3
+
+
+def two_object_bundle(width, height, copies=7, **meta_kw):
+    """Two different objects (the tiny scene and a small atrium) in one layout, placed `copies` times in turn."""
+    a = scenes.tiny_scene(3)
+    b = scenes.generate("atrium", 1500, seed=5, texture_size=32)
+    # bring the atrium to the tiny scene's size so that both show up in one view
+    pa = np.asarray(a["positions"], np.float32).reshape(-1, 3)
+    pb = np.asarray(b["positions"], np.float32).reshape(-1, 3)
+    scale = np.float32((pa.max(axis=0) - pa.min(axis=0)).max() / (pb.max(axis=0) - pb.min(axis=0)).max())
+    b = dict(b, positions=(pb * scale).reshape(-1), triangles=np.asarray(b["triangles"], np.float32) * scale)
+    sc, object_first = scenes.concat_scenes([a, b])
+    flat, objects = host.bvh_flatten_objects(sc["triangles"], object_first)
+    which = np.arange(copies, dtype=np.uint32) % 2
+    m = assorted_transforms(a, copies, seed=11)
+    top = host.bvh_flatten_placements(objects, which, m)
+    # camera over the placements
+    centre = m[:, :, 3].mean(axis=0).astype(np.float64)
+    size = float(np.ptp(m[:, :, 3], axis=0).max()) + 2.0
+    pos = centre + np.array([0.3, 0.5, -0.6]) * size
+    cam = host.camera(pos, centre, 60.0, width / height, 0.0, float(np.linalg.norm(pos - centre)))
+    nodes = np.zeros((1, 8), np.uint32); nodes[0, 3] = 0xFFFFFFFF      # the threaded tree is not walked
+    return dict(sc, nodes=nodes, flat=flat, flat_instances=top, meta=scenes.pack_metadata(cam, width, height, **meta_kw), width=width, height=height,
+                object_first=object_first, object_of_copy=which, objects=objects)
+
+
+def test_objects_share_one_layout():
+    b = two_object_bundle(32, 24)
+    h, nodes, tris = parse(b["flat"])
+    first = b["object_first"]
+    assert h["triangle_count"] == first[-1] and sorted(tris.view(np.int32)[:, 7].tolist()) == list(range(first[-1])), "primitive ids are global"
+    assert h["root"] == b["objects"]["root"][0] and h["max_depth"] == b["objects"]["max_depth"].max()
+    # each object's tree reaches exactly its own triangles
+    ni = nodes.view(np.int32)
+
+    def reach(ref, out):
+        if ref < 0:
+            r = ~ref
+            out.update(range(r >> 2, (r >> 2) + (r & 3) + 1))
+            return
+        for k in range(4):
+            c = int(ni[ref, 4 + k])
+            if c != -2 ** 31:
+                reach(c, out)
+
+    seen_all = set()
+    for k, o in enumerate(b["objects"]):
+        got = set()
+        reach(int(o["root"]), got)
+        prims = set(tris.view(np.int32)[sorted(got), 7].tolist())
+        assert prims == set(range(int(first[k]), int(first[k + 1]))), f"object {k}"
+        assert not (got & seen_all)
+        seen_all |= got
+        tri = b["triangles"][first[k]:first[k + 1]].reshape(-1, 3)
+        assert np.array_equal(o["box_min"], tri.min(axis=0)) and np.array_equal(o["box_max"], tri.max(axis=0))
+
+
+def test_copies_of_two_objects():
+    """Every copy shows the object it names: a primary hit's primitive lies in that object's run of triangles."""
+    b = two_object_bundle(96, 64, max_bounce=3)
+    img, counters, cap = oracle_frames(b, 2, use_flat=True, aov=True)
+    named = cap[0][..., 0]
+    hit = named >= 0
+    assert hit.mean() > 0.05
+    total = int(b["object_first"][-1])
+    copy, prim = named[hit] // total, named[hit] % total
+    assert len(np.unique(copy)) >= 4
+    obj = b["object_of_copy"][copy]
+    assert ((prim >= b["object_first"][obj]) & (prim < b["object_first"][obj + 1])).all()
+    assert set(np.unique(obj).tolist()) == {0, 1}, "both objects are in view"
+    assert np.isfinite(img).all() and img[..., :3].std() > 0.01
