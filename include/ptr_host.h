@@ -56,7 +56,8 @@ void ptrh_camera(const float pos[3], const float target[3], float v_fov, float a
 
 /* ---- glTF -> flat scene arrays: gltf::gltf(path) + the flattening loop of scene::scene -- reference:
  * src/gltf.cpp:14-195, src/mesh.cpp:5-37, src/scene.cpp:84-176.  *scene_out is an opaque flat scene; free it with
- * ptrh_scene_free.  apply_transforms 0 = node transforms ignored (what the reference does), 1 = applied.
+ * ptrh_scene_free.  apply_transforms 0 = node transforms ignored (what the reference does), 1 = applied, 2 = instanced
+ * (gltf::flatten_instanced, an extension: every mesh once, untransformed, and one placement per node that shows it).
  * wide_indices -1 = the reference's packed index words unless the scene has more than 2^24 vertices or material records,
  * 0 = packed (fails for such a scene), 1 = always the 4-word extension (v0, v1, v2, material per triangle). */
 int32_t ptrh_gltf_load(const char* path, int32_t apply_transforms, int32_t wide_indices, void** scene_out);
@@ -64,6 +65,9 @@ int32_t ptrh_gltf_load(const char* path, int32_t apply_transforms, int32_t wide_
 int32_t ptrh_scene_load(const char* path, void** scene_out);
 /* counts = { index words in total, vertices, material records, textures, index words per triangle (3 or 4) } */
 int32_t ptrh_scene_counts(const void* scene, uint64_t counts[5]);
+/* Instanced scenes: counts = { objects, placements }; object_first u32[objects + 1] (triangle offsets), object_of_copy
+ * u32[placements], object_to_world f32[12 * placements] (rows of 3x3 part, translation).  Array pointers may be NULL. */
+int32_t ptrh_scene_placements(const void* scene, uint64_t counts[2], uint32_t* object_first, uint32_t* object_of_copy, float* object_to_world);
 /* Copies the arrays out (any pointer may be NULL): indices u32[counts[0]] (3 words per triangle: 24-bit vertex id | one byte
  * of the material id, src/scene.cpp:140-142; or 4 plain words per triangle, see counts[4]), positions/normals f32[3 * vertices], uvs f32[2 * vertices], materials
  * counts[2] records of 32 bytes { f32 base_color[4]; u32 albedo_texture, mr_texture (1-based, 0 = none);

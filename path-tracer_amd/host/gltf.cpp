@@ -382,6 +382,31 @@ void gltf::load_materials() {
     }
 }
 
+namespace {
+// Index words and material records of one mesh, appended to the flat arrays: indices made absolute, one material record
+// per submesh (src/scene.cpp:132-163).
+void append_submeshes(scene_source& out, const Mesh& mesh, const std::vector<scene_source::source_material>& materials, size_t vertices_offset) {
+    const auto& mesh_indices = mesh.get_indices();
+    for (const auto& submesh : mesh.get_submeshes()) {
+        const size_t vertex_offset = vertices_offset + submesh.vertex_offset;
+        const size_t material_id = out.materials.size();
+        for (size_t e = 0; e < submesh.element_count; e++) {
+            const size_t at = submesh.index_offset + e * 3;
+            if (out.index_words == 4) {
+                for (int k = 0; k < 3; k++) out.indices.push_back((uint32_t)(mesh_indices[at + k] + vertex_offset));
+                out.indices.push_back((uint32_t)material_id);
+                continue;
+            }
+            // vertex id in the low 24 bits, one byte of the material id on top of each word (src/scene.cpp:140-142)
+            out.indices.push_back((uint32_t)((mesh_indices[at] + vertex_offset) | (0xff000000u & (material_id << 8))));
+            out.indices.push_back((uint32_t)((mesh_indices[at + 1] + vertex_offset) | (0xff000000u & (material_id << 16))));
+            out.indices.push_back((uint32_t)((mesh_indices[at + 2] + vertex_offset) | (0xff000000u & (material_id << 24))));
+        }
+        out.materials.push_back(materials[submesh.material]);
+    }
+}
+}  // namespace
+
 scene_source gltf::flatten(bool apply_transforms, int wide_indices) const {
     scene_source out;
     // what the flat scene will hold, to pick the index layout before the first word is written
@@ -425,7 +450,6 @@ scene_source gltf::flatten(bool apply_transforms, int wide_indices) const {
             const auto& mesh_positions = mesh->get_attribute(ATTRIBUTE_TYPE::POSITION);
             const auto& mesh_normals = mesh->get_attribute(ATTRIBUTE_TYPE::NORMAL);
             const auto& mesh_uvs_0 = mesh->get_attribute(ATTRIBUTE_TYPE::UV_0);
-            const auto& mesh_indices = mesh->get_indices();
 
             if (!apply_transforms) {
                 out.positions.insert(out.positions.end(), mesh_positions.begin(), mesh_positions.end());
@@ -449,23 +473,7 @@ scene_source gltf::flatten(bool apply_transforms, int wide_indices) const {
             }
             out.uvs.insert(out.uvs.end(), mesh_uvs_0.begin(), mesh_uvs_0.end());
 
-            for (const auto& submesh : mesh->get_submeshes()) {
-                const size_t vertex_offset = vertices_offset + submesh.vertex_offset;
-                const size_t material_id = out.materials.size();
-                for (size_t e = 0; e < submesh.element_count; e++) {
-                    const size_t at = submesh.index_offset + e * 3;
-                    if (out.index_words == 4) {
-                        for (int k = 0; k < 3; k++) out.indices.push_back((uint32_t)(mesh_indices[at + k] + vertex_offset));
-                        out.indices.push_back((uint32_t)material_id);
-                        continue;
-                    }
-                    // vertex id in the low 24 bits, one byte of the material id on top of each word (src/scene.cpp:140-142)
-                    out.indices.push_back((uint32_t)((mesh_indices[at] + vertex_offset) | (0xff000000u & (material_id << 8))));
-                    out.indices.push_back((uint32_t)((mesh_indices[at + 1] + vertex_offset) | (0xff000000u & (material_id << 16))));
-                    out.indices.push_back((uint32_t)((mesh_indices[at + 2] + vertex_offset) | (0xff000000u & (material_id << 24))));
-                }
-                out.materials.push_back(materials[submesh.material]);
-            }
+            append_submeshes(out, *mesh, materials, vertices_offset);
             vertices_offset += mesh->vertices_count();
         }
         for (const node& child : cur.n->children) {
@@ -474,5 +482,72 @@ scene_source gltf::flatten(bool apply_transforms, int wide_indices) const {
             nodes_to_load.push(next);
         }
     }
+    return out;
+}
+
+// Each mesh once, every node that shows it a placement: what a glTF file means by sharing a mesh between nodes.
+scene_source gltf::flatten_instanced(int wide_indices) const {
+    scene_source out;
+    {
+        size_t total_vertices = 0, total_materials = 0;
+        for (const Mesh& m : meshes) { total_vertices += m.vertices_count(); total_materials += m.get_submeshes().size(); }
+        const bool fits = total_vertices < (1u << 24) && total_materials < (1u << 24);
+        if (wide_indices == 0 && !fits) throw gltf_error("gltf: more than 2^24 vertices or material records do not fit the packed index words");
+        if (total_vertices > 0xffffffffull) throw gltf_error("gltf: more than 2^32 vertices");
+        out.index_words = (wide_indices == 1 || (wide_indices < 0 && !fits)) ? 4u : 3u;
+    }
+    for (uint32_t image_index : textures) {
+        const raw_image& im = images[image_index];
+        scene_source::source_texture t;
+        t.width = (uint32_t)im.width; t.height = (uint32_t)im.height;
+        t.rgba = im.data;
+        out.textures.push_back(std::move(t));
+    }
+    std::vector<int32_t> object_of_mesh(meshes.size(), -1);
+    out.object_first.push_back(0);
+    struct pending { const node* n; double world[16]; };
+    std::queue<pending> nodes_to_load;
+    {
+        pending root; root.n = &root_node;
+        std::memcpy(root.world, root_node.matrix, sizeof root.world);
+        nodes_to_load.push(root);
+    }
+    size_t vertices_offset = 0;
+    while (!nodes_to_load.empty()) {
+        const pending cur = nodes_to_load.front();
+        nodes_to_load.pop();
+        if (cur.n->mesh != nullptr) {
+            const Mesh* mesh = cur.n->mesh;
+            const size_t mesh_index = (size_t)(mesh - meshes.data());
+            if (object_of_mesh[mesh_index] < 0 && !mesh->get_indices().empty()) {
+                const auto& p = mesh->get_attribute(ATTRIBUTE_TYPE::POSITION);
+                const auto& n = mesh->get_attribute(ATTRIBUTE_TYPE::NORMAL);
+                const auto& uv = mesh->get_attribute(ATTRIBUTE_TYPE::UV_0);
+                out.positions.insert(out.positions.end(), p.begin(), p.end());
+                out.normals.insert(out.normals.end(), n.begin(), n.end());
+                out.uvs.insert(out.uvs.end(), uv.begin(), uv.end());
+                append_submeshes(out, *mesh, materials, vertices_offset);
+                vertices_offset += mesh->vertices_count();
+                object_of_mesh[mesh_index] = (int32_t)out.object_first.size() - 1;
+                out.object_first.push_back((uint32_t)out.triangle_count());
+            }
+            if (object_of_mesh[mesh_index] >= 0) {
+                scene_source::placement place;
+                place.object = (uint32_t)object_of_mesh[mesh_index];
+                const double* m = cur.world;  // column-major; rows of (3x3 part, translation)
+                for (int r = 0; r < 3; r++) {
+                    place.object_to_world[r * 4] = (float)m[r]; place.object_to_world[r * 4 + 1] = (float)m[4 + r];
+                    place.object_to_world[r * 4 + 2] = (float)m[8 + r]; place.object_to_world[r * 4 + 3] = (float)m[12 + r];
+                }
+                out.placements.push_back(place);
+            }
+        }
+        for (const node& child : cur.n->children) {
+            pending next; next.n = &child;
+            mat_mul(cur.world, child.matrix, next.world);
+            nodes_to_load.push(next);
+        }
+    }
+    if (out.placements.empty()) throw gltf_error("gltf: no node shows a mesh");
     return out;
 }

@@ -45,6 +45,11 @@ public:
     // when it cannot), 1 = always 4 words.
     scene_source flatten(bool apply_transforms = false, int wide_indices = -1) const;
 
+    // Instancing (an extension): each mesh appears ONCE in the arrays, untransformed, as an object of its own, and every
+    // node that shows it becomes a placement with the node's world matrix -- node transforms are honoured without copying
+    // geometry.  The scene class renders such a source through a top-level tree (ptr_bvh_bind_instances).
+    scene_source flatten_instanced(int wide_indices = -1) const;
+
     const std::vector<Mesh>& get_meshes() const { return meshes; }
     const std::vector<scene_source::source_material>& get_materials() const { return materials; }
     const std::vector<raw_image>& get_images() const { return images; }

@@ -2,7 +2,7 @@
 // Builds the scene, wires the compute render pass exactly as src/main.cpp:261-270 does, renders `spp`
 // frames with the per-frame protocol of src/main.cpp:406-416 and writes the accumulated image.
 //
-//   ptr_headless --scene file.{ptrscene,gltf,glb} [--apply-transforms] [--gpu-bvh] [--copies NX NZ] --width W --height H --spp N [--max-bounce B] [--min-bounce B]
+//   ptr_headless --scene file.{ptrscene,gltf,glb} [--apply-transforms | --instanced] [--gpu-bvh] [--copies NX NZ] --width W --height H --spp N [--max-bounce B] [--min-bounce B]
 //                [--dof 0|1] [--downscale D] [--debug-bvh 0|1] [--pipeline compute|compute.megakernel|compute.wavefront]
 //                [--pos x y z] [--target x y z] [--fov deg] [--aperture a] [--focus f] [--out image.pfm|image.ppm|image.png]
 #include <chrono>
@@ -46,9 +46,10 @@ void write_image(const std::string& path, const std::vector<float>& rgba, uint32
     std::fclose(f);
 }
 // .gltf / .glb go through the glTF loader, anything else is read as a .ptrscene file
-scene_source load_source(const std::string& path, bool apply_transforms) {
+scene_source load_source(const std::string& path, bool apply_transforms, bool instanced) {
     const size_t dot = path.find_last_of('.');
     const std::string ext = dot == std::string::npos ? std::string() : path.substr(dot);
+    if ((ext == ".gltf" || ext == ".glb") && instanced) return gltf(path).flatten_instanced();
     if (ext == ".gltf" || ext == ".glb") return gltf(path).flatten(apply_transforms);
     return scene_source::load(path);
 }
@@ -56,7 +57,7 @@ scene_source load_source(const std::string& path, bool apply_transforms) {
 
 int main(int argc, char** argv) {
     std::string scene_path, out_path, pipeline = "compute";
-    bool apply_transforms = false, gpu_bvh = false;
+    bool apply_transforms = false, gpu_bvh = false, instanced = false;
     uint32_t copies_x = 1, copies_z = 1;
     uint32_t width = 400, height = 225, spp = 1, max_bounce = 3, min_bounce = 1, dof = 0, debug_bvh = 0;
     int32_t downscale = 1;
@@ -67,6 +68,7 @@ int main(int argc, char** argv) {
         if (is("--scene")) scene_path = next();
         else if (is("--apply-transforms")) apply_transforms = true;
         else if (is("--gpu-bvh")) gpu_bvh = true;
+        else if (is("--instanced")) instanced = true;
         else if (is("--copies")) { copies_x = (uint32_t)std::atoi(next()); copies_z = (uint32_t)std::atoi(next()); }
         else if (is("--out")) out_path = next();
         else if (is("--pipeline")) pipeline = next();
@@ -92,7 +94,7 @@ int main(int argc, char** argv) {
         const float aspect_ratio = (float)width / (float)height;
         const auto t_build = std::chrono::steady_clock::now();
         scene main_scene(camera(point3{ pos[0], pos[1], pos[2] }, point3{ target[0], target[1], target[2] }, v_fov, aspect_ratio, aperture, focus), width, height,
-                         load_source(scene_path, apply_transforms), pipeline != "compute.megakernel", gpu_bvh);
+                         load_source(scene_path, apply_transforms, instanced), pipeline != "compute.megakernel", gpu_bvh);
         main_scene.meta.max_bounce = max_bounce; main_scene.meta.min_bounce = min_bounce;
         main_scene.meta.enable_dof = dof; main_scene.meta.debug_bvh = debug_bvh; main_scene.meta.downscale_factor = downscale;
         if (copies_x * copies_z > 1) main_scene.place_copies_on_grid(copies_x, copies_z);  // the scene repeated on a grid, through a top-level tree

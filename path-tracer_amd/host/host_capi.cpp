@@ -174,7 +174,7 @@ int32_t ptrh_gltf_load(const char* path, int32_t apply_transforms, int32_t wide_
     try {
         if (!path || !scene_out) { g_last_error = "ptrh_gltf_load: null argument"; return -1; }
         const gltf model{ std::string(path) };
-        *scene_out = new scene_source(model.flatten(apply_transforms != 0, wide_indices));
+        *scene_out = new scene_source(apply_transforms == 2 ? model.flatten_instanced(wide_indices) : model.flatten(apply_transforms != 0, wide_indices));
         return 0;
     } catch (const std::exception& e) {
         g_last_error = e.what();
@@ -221,6 +221,19 @@ int32_t ptrh_scene_texture(const void* scene, uint32_t index, uint32_t* width, u
     if (width) *width = t.width;
     if (height) *height = t.height;
     if (rgba) std::memcpy(rgba, t.rgba.data(), t.rgba.size());
+    return 0;
+}
+
+int32_t ptrh_scene_placements(const void* scene, uint64_t counts[2], uint32_t* object_first, uint32_t* object_of_copy, float* object_to_world) {
+    if (!scene || !counts) { g_last_error = "ptrh_scene_placements: null argument"; return -1; }
+    const scene_source* s = (const scene_source*)scene;
+    counts[0] = s->object_first.empty() ? 0 : s->object_first.size() - 1;
+    counts[1] = s->placements.size();
+    if (object_first) std::memcpy(object_first, s->object_first.data(), s->object_first.size() * 4);
+    for (size_t i = 0; i < s->placements.size(); i++) {
+        if (object_of_copy) object_of_copy[i] = s->placements[i].object;
+        if (object_to_world) std::memcpy(object_to_world + i * 12, s->placements[i].object_to_world, sizeof(float) * 12);
+    }
     return 0;
 }
 

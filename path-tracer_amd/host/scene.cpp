@@ -89,7 +89,21 @@ scene::scene(const camera& cam, uint32_t width, uint32_t height, const scene_sou
     bvh_buffer = upload(packed_nodes.data(), packed_nodes.size() * sizeof(packed_bvh_node));
     materials_buffer = upload(materials.data(), materials.size() * sizeof(gpu_material));
 
-    if (flatten_bvh && gpu_bvh) {
+    if (flatten_bvh && !src.placements.empty()) {
+        // the scene is placed copies of its objects: one layout with a tree per object, and a top level over the copies
+        std::vector<flat_bvh_object> objects;
+        const std::vector<uint8_t> flat = bvh::flatten_objects(triangles, ranks, src.object_first, objects);
+        flat_bvh_buffer = upload(flat.data(), flat.size());
+        hiprenderer::check(ptr_bvh_bind_flat(hiprenderer::api, bvh_buffer->device_buffer, flat_bvh_buffer->device_buffer), "ptr_bvh_bind_flat");
+        std::vector<uint32_t> which;
+        std::vector<float> transforms;
+        for (const auto& p : src.placements) { which.push_back(p.object); transforms.insert(transforms.end(), p.object_to_world, p.object_to_world + 12); }
+        const std::vector<uint8_t> top = bvh::flatten_instances(objects, which, transforms);
+        instances_buffer = upload(top.data(), top.size());
+        hiprenderer::check(ptr_bvh_bind_instances(hiprenderer::api, flat_bvh_buffer->device_buffer, instances_buffer->device_buffer), "ptr_bvh_bind_instances");
+        copy_count = src.placements.size();
+        bvh_mode += " + placements";
+    } else if (flatten_bvh && gpu_bvh) {
         ptr_handle built = 0;
         hiprenderer::check(ptr_bvh_build_flat(hiprenderer::api, indices_buffer->device_buffer, positions_buffer->device_buffer, (uint32_t)triangle_count, &built),
                            "ptr_bvh_build_flat");

@@ -21,6 +21,13 @@ struct scene_source {
     struct source_texture { uint32_t width, height; std::vector<uint8_t> rgba; };
     std::vector<source_texture> textures;
 
+    // Instancing (optional, an extension): triangles [object_first[k], object_first[k + 1]) form object k, and the scene
+    // is the placements -- copies of objects through affine object-to-world matrices (rows of 3x3 part, translation) --
+    // instead of the triangle soup itself.  Empty = no instancing.
+    std::vector<uint32_t> object_first;
+    struct placement { uint32_t object; float object_to_world[12]; };
+    std::vector<placement> placements;
+
     static scene_source load(const std::string& path);  // .ptrscene file, see scene_source.cpp
 };
 

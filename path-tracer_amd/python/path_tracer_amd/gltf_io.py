@@ -117,11 +117,13 @@ def _json_float(x):
 
 
 def save_gltf(scene, directory, name="scene", primitives_per_mesh=4, container="gltf", image_format="png", embed=False,
-              index_type="auto", interleave=False):
+              index_type="auto", interleave=False, placements=None):
     """Writes `scene` as <directory>/<name>.gltf (+ .bin + one image file per texture), or <name>.glb.
     The node tree is a binary heap (children of node i are 2i+1, 2i+2), so a breadth-first walk meets the meshes in
     file order and the loader's flat arrays come out identical to `scene`'s.
-    interleave: positions/normals/uvs of a primitive share one strided buffer view (byteStride 32)."""
+    interleave: positions/normals/uvs of a primitive share one strided buffer view (byteStride 32).
+    placements: list of (mesh number, (3, 4) object-to-world matrix) -- the node list then holds one node per placement,
+    in that order, instead of one node per mesh (meshes shared between nodes: what an instancing loader looks for)."""
     os.makedirs(directory, exist_ok=True)
     positions = np.asarray(scene["positions"], np.float32).reshape(-1, 3)
     normals = np.asarray(scene["normals"], np.float32).reshape(-1, 3)
@@ -191,6 +193,16 @@ def save_gltf(scene, directory, name="scene", primitives_per_mesh=4, container="
             nd["children"] = kids
         nodes.append(nd)
 
+    if placements is not None:
+        nodes = []
+        for k, (mesh_number, m) in enumerate(placements):
+            m = np.asarray(m, np.float64).reshape(3, 4)
+            column_major = [m[r, c] for c in range(4) for r in range(3)]
+            column_major = column_major[0:3] + [0.0] + column_major[3:6] + [0.0] + column_major[6:9] + [0.0] + column_major[9:12] + [1.0]
+            nodes.append({"name": f"placement{k}", "mesh": int(mesh_number), "matrix": [_json_float(x) for x in column_major]})
+        n_nodes = len(nodes)
+    scene_nodes = list(range(n_nodes)) if placements is not None else ([0] if n_nodes else [])
+
     textures = [t for t in scene["textures"] if t is not None]
     images = []
     for i, t in enumerate(textures):
@@ -223,7 +235,7 @@ def save_gltf(scene, directory, name="scene", primitives_per_mesh=4, container="
         mats.append({"pbrMetallicRoughness": pbr})
 
     doc = {"asset": {"version": "2.0", "generator": "path_tracer_amd.gltf_io"}, "scene": 0,
-           "scenes": [{"nodes": [0] if n_nodes else []}], "nodes": nodes, "meshes": meshes, "materials": mats,
+           "scenes": [{"nodes": scene_nodes}], "nodes": nodes, "meshes": meshes, "materials": mats,
            "textures": [{"source": i, "sampler": 0} for i in range(len(textures))], "images": images,
            "samplers": [{"magFilter": 9729, "minFilter": 9729, "wrapS": 10497, "wrapT": 10497}],
            "accessors": accessors, "bufferViews": views}

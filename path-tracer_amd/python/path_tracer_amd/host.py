@@ -37,6 +37,7 @@ def lib():
         L.ptrh_scene_counts.argtypes = [vp, C.POINTER(C.c_uint64)]
         L.ptrh_scene_arrays.argtypes = [vp, vp, vp, vp, vp, vp]
         L.ptrh_scene_texture.argtypes = [vp, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), vp]
+        L.ptrh_scene_placements.argtypes = [vp, C.POINTER(C.c_uint64), vp, vp, vp]
         L.ptrh_scene_free.argtypes = [vp]
         L.ptrh_image_decode.argtypes = [vp, C.c_uint64, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(vp)]
         L.ptrh_image_encode_png.argtypes = [vp, C.c_uint32, C.c_uint32, C.POINTER(vp), C.POINTER(C.c_uint64)]
@@ -169,7 +170,7 @@ def camera(pos, target, v_fov, aspect, aperture, focus, ops=()):
 
 
 HOST_SYMBOLS = ["ptrh_last_error", "ptrh_sizes", "ptrh_bvh_build", "ptrh_bvh_visit_ranks", "ptrh_bvh_flatten", "ptrh_bvh_flatten_instances", "ptrh_bvh_flatten_objects", "ptrh_bvh_flatten_placements", "ptrh_free", "ptrh_camera",
-                "ptrh_gltf_load", "ptrh_scene_load", "ptrh_scene_counts", "ptrh_scene_arrays", "ptrh_scene_texture", "ptrh_scene_free",
+                "ptrh_gltf_load", "ptrh_scene_load", "ptrh_scene_counts", "ptrh_scene_arrays", "ptrh_scene_texture", "ptrh_scene_placements", "ptrh_scene_free",
                 "ptrh_image_decode", "ptrh_image_encode_png", "ptrh_json_dump"]
 
 # 32-byte material record of a flat scene before upload (texture numbers are 1-based, 0 = none)
@@ -208,6 +209,14 @@ def _scene_to_dict(handle):
             textures.append(t)
         out["textures"] = textures
         out["index_words"] = index_words
+        pc = (C.c_uint64 * 2)()
+        if L.ptrh_scene_placements(handle, pc, None, None, None) != 0:
+            raise HostError(L.ptrh_last_error().decode())
+        if pc[1]:
+            out["object_first"] = np.zeros(int(pc[0]) + 1, np.uint32)
+            out["object_of_copy"] = np.zeros(int(pc[1]), np.uint32)
+            out["object_to_world"] = np.zeros((int(pc[1]), 3, 4), np.float32)
+            L.ptrh_scene_placements(handle, pc, out["object_first"].ctypes.data, out["object_of_copy"].ctypes.data, out["object_to_world"].ctypes.data)
         vid = (out["indices"] & np.uint32(0x00FFFFFF)) if index_words == 3 else out["indices"].reshape(-1, 4)[:, :3].reshape(-1)
         out["triangles"] = np.ascontiguousarray(out["positions"].reshape(-1, 3)[vid].reshape(-1, 9))
         out["primitive_count"] = n_mat
@@ -216,10 +225,11 @@ def _scene_to_dict(handle):
         L.ptrh_scene_free(handle)
 
 
-def gltf_load(path, apply_transforms=False, wide_indices=-1):
-    """gltf(path).flatten(): the flat scene arrays (same dict layout as scenes.generate, without a camera)."""
+def gltf_load(path, apply_transforms=False, wide_indices=-1, instanced=False):
+    """gltf(path).flatten(): the flat scene arrays (same dict layout as scenes.generate, without a camera).
+    instanced: gltf(path).flatten_instanced() -- every mesh once plus object_first / object_of_copy / object_to_world."""
     h = C.c_void_p()
-    if lib().ptrh_gltf_load(os.fsencode(path), 1 if apply_transforms else 0, wide_indices, C.byref(h)) != 0:
+    if lib().ptrh_gltf_load(os.fsencode(path), 2 if instanced else (1 if apply_transforms else 0), wide_indices, C.byref(h)) != 0:
         raise HostError(lib().ptrh_last_error().decode())
     return _scene_to_dict(h)
 

@@ -332,3 +332,34 @@ def test_gltf_errors(tmp_path):
     (tmp_path / "garbage.gltf").write_text("{ not json")
     with pytest.raises(host.HostError):
         host.gltf_load(str(tmp_path / "garbage.gltf"))
+
+
+def test_instanced_flattening_keeps_every_mesh_once(tmp_path):
+    """gltf::flatten_instanced: meshes shared between nodes come out once, untransformed, each an object of its own, and
+    every node becomes a placement with its world matrix."""
+    from common import make_bundle
+    b = make_bundle("atrium", 3000, 32, 24)
+    n_meshes = (len(b["materials"]) + 3) // 4
+    rng = np.random.default_rng(3)
+    mats = []
+    for copy in range(3):
+        m = np.zeros((3, 4), np.float32)
+        m[:, :3] = np.eye(3) * (1.0 + 0.25 * copy)
+        m[0, 1] = 0.125 * copy
+        m[:, 3] = rng.uniform(-20, 20, 3).astype(np.float32)
+        mats.append(m)
+    placements = [(mesh, mats[copy]) for copy in range(3) for mesh in range(n_meshes)]
+    path = gltf_io.save_gltf(b, str(tmp_path), "placed", placements=placements)
+    sc = host.gltf_load(path, instanced=True)
+    for key in ("positions", "normals", "uvs"):
+        assert np.array_equal(sc[key], b[key]), key
+    assert np.array_equal(sc["indices"], b["indices"])
+    assert len(sc["object_first"]) == n_meshes + 1 and sc["object_first"][0] == 0 and sc["object_first"][-1] == len(b["indices"]) // 3
+    ranges = gltf_io.primitive_ranges(b)
+    for k in range(n_meshes):
+        assert sc["object_first"][k] == ranges[4 * k][0]
+    assert np.array_equal(sc["object_of_copy"], np.array([mesh for _, mesh in [(c, m) for c in range(3) for m in range(n_meshes)]], np.uint32))
+    assert np.array_equal(sc["object_to_world"], np.stack([mats[copy] for copy in range(3) for _ in range(n_meshes)]))
+    # the plain flattening of the same file writes every node's mesh out
+    plain = host.gltf_load(path, apply_transforms=True)
+    assert len(plain["indices"]) == 3 * len(b["indices"])

@@ -146,3 +146,42 @@ def test_headless_driver_places_copies_on_a_grid(tmp_path):
     assert len(np.unique(hit[hit >= 0] // b["triangles"].shape[0])) == NX * NZ, "every copy is in view"
     img = read_ptrf(out_file)
     assert np.array_equal(img, ref), f"{int((np.abs(img - ref).max(axis=2) > 0).sum())} pixels differ\n{r.stderr}"
+
+
+def test_headless_driver_renders_shared_meshes_as_placements(tmp_path):
+    """--instanced: gltf::flatten_instanced -> scene (bvh::flatten_objects + flatten_instances) -> kernels.  The image equals the
+    oracle's two-level traversal over the same objects and placements."""
+    from path_tracer_amd import host
+    W, H, SPP = 96, 54, 2
+    b = make_bundle("atrium", 3000, W, H, max_bounce=4)
+    n_meshes = (len(b["materials"]) + 3) // 4
+    P = np.asarray(b["positions"], np.float32).reshape(-1, 3)
+    size = float((P.max(axis=0) - P.min(axis=0)).max())
+    mats = []
+    for copy in range(3):
+        c, s = np.cos(0.7 * copy), np.sin(0.7 * copy)
+        m = np.zeros((3, 4), np.float32)
+        m[:, :3] = np.array([[c, 0, s], [0, 1, 0], [-s, 0, c]]) * (1.0 - 0.2 * copy)
+        m[:, 3] = [(copy - 1) * size * 1.3, 0.0, 0.2 * copy * size]
+        mats.append(m)
+    placements = [(mesh, mats[copy]) for copy in range(3) for mesh in range(n_meshes)]
+    scene_file = gltf_io.save_gltf(b, str(tmp_path), "placed", placements=placements)
+    out_file = str(tmp_path / "out.pfm")
+    pos, target = [0.0, 1.5 * size, -1.25 * size], [0.0, 0.0, 0.0]
+    cmd = [HEADLESS, "--scene", scene_file, "--instanced", "--width", str(W), "--height", str(H), "--spp", str(SPP), "--max-bounce", "4",
+           "--out", out_file, "--pos", *map(str, pos), "--target", *map(str, target), "--fov", "60", "--aperture", "0", "--focus", "10"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    assert f"x {len(placements)}" in r.stderr and "placements" in r.stderr
+
+    object_first = np.array([gltf_io.primitive_ranges(b)[4 * k][0] for k in range(n_meshes)] + [b["triangles"].shape[0]], np.uint32)
+    flat, objects = host.bvh_flatten_objects(b["triangles"], object_first, b["ranks"])
+    which = np.array([mesh for _ in range(3) for mesh in range(n_meshes)], np.uint32)
+    m = np.stack([mats[copy] for copy in range(3) for _ in range(n_meshes)])
+    cam = host.camera(pos, target, 60.0, W / H, 0.0, 10.0)
+    two = dict(b, flat=flat, flat_instances=host.bvh_flatten_placements(objects, which, m), meta=scenes.pack_metadata(cam, W, H, max_bounce=4))
+    ref, _, aov = oracle_frames(two, SPP, use_flat=True, aov=True)
+    hit = aov[0][..., 0]
+    assert (hit >= 0).mean() > 0.08 and len(np.unique(hit[hit >= 0] // b["triangles"].shape[0])) >= 10, "several placements are in view"
+    img = read_ptrf(out_file)
+    assert np.array_equal(img, ref), f"{int((np.abs(img - ref).max(axis=2) > 0).sum())} pixels differ\n{r.stderr}"
