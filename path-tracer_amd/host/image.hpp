@@ -2,8 +2,8 @@
 // (src/gltf.cpp:103-112: stbi_load(path, &w, &h, &channels, 4)); this is an independent decoder with the same
 // contract: 8-bit RGBA, row-major from the top-left, no vertical flip.
 //   PNG  (all colour types, bit depths 1-16, tRNS, Adam7): lossless, so the texels are defined by the file.
-//   JPEG (baseline and extended sequential Huffman, 8-bit, 1 or 3 components, any sampling factors, restart
-//        intervals): the standard leaves IDCT rounding and chroma upsampling to the decoder, texels can differ
+//   JPEG (baseline, extended sequential and progressive Huffman, 8-bit, 1 or 3 components, any sampling factors,
+//        interleaved and per-component scans, restart intervals): the standard leaves IDCT rounding and chroma upsampling to the decoder, texels can differ
 //        by a few code values from another decoder's.
 #ifndef PTR_IMAGE_HPP_
 #define PTR_IMAGE_HPP_

@@ -1,6 +1,8 @@
-// JPEG decoder (ITU-T T.81): baseline and extended sequential DCT, Huffman coding, 8-bit samples, 1 (grey) or
-// 3 (YCbCr, or RGB with an Adobe transform-0 marker) components, any sampling factors up to 4, restart
-// intervals, written against the standard.  Progressive, arithmetic-coded, lossless and 12-bit files are rejected.
+// JPEG decoder (ITU-T T.81): baseline, extended sequential and progressive DCT (spectral selection and successive
+// approximation, T.81 annex G), Huffman coding, 8-bit samples, 1 (grey) or 3 (YCbCr, or RGB with an Adobe
+// transform-0 marker) components, any sampling factors up to 4, interleaved and per-component scans, restart
+// intervals, written against the standard.  Arithmetic-coded, lossless, hierarchical and 12-bit files are rejected.
+// Every scan adds to per-component coefficient arrays; dequantisation and the inverse DCT run once, after the last scan.
 #include "image.hpp"
 
 #include <cmath>
@@ -36,7 +38,9 @@ struct huff_table {
 struct component {
     int id = 0, h = 1, v = 1, tq = 0, td = 0, ta = 0;
     int blocks_w = 0, blocks_h = 0;   // padded to whole MCUs
+    int own_blocks_w = 0, own_blocks_h = 0;  // blocks that hold picture samples: what a scan of this component alone codes
     int pred = 0;
+    std::vector<int16_t> coef;        // blocks_w * blocks_h blocks of 64 coefficients in natural order, not dequantised
     std::vector<uint8_t> plane;       // blocks_w*8 x blocks_h*8 samples
 };
 
@@ -139,19 +143,19 @@ raw_image decode_jpeg(const uint8_t* bytes, size_t size) {
     std::vector<component> comps;
     int width = 0, height = 0, restart_interval = 0;
     int adobe_transform = -1;
-    bool have_frame = false, decoded = false;
-    int hmax = 1, vmax = 1;
+    bool have_frame = false, decoded = false, progressive = false, scan_seen = false;
+    int hmax = 1, vmax = 1, mcus_x = 0, mcus_y = 0;
 
     size_t pos = 2;
     while (!decoded) {
         // next marker
-        if (pos + 2 > size) throw image_error("jpeg: truncated before the scan");
+        if (pos + 2 > size) { if (scan_seen) break; throw image_error("jpeg: truncated before the scan"); }
         if (bytes[pos] != 0xFF) throw image_error("jpeg: marker expected");
         while (pos < size && bytes[pos] == 0xFF) pos++;
         if (pos >= size) throw image_error("jpeg: truncated marker");
         const uint8_t marker = bytes[pos++];
         if (marker == 0xD8 || (marker >= 0xD0 && marker <= 0xD7) || marker == 0x01) continue;  // no payload
-        if (marker == 0xD9) throw image_error("jpeg: end of image before any scan");
+        if (marker == 0xD9) { if (scan_seen) break; throw image_error("jpeg: end of image before any scan"); }
         if (pos + 2 > size) throw image_error("jpeg: truncated segment");
         const size_t seg_len = be16(bytes + pos);
         if (seg_len < 2 || pos + seg_len > size) throw image_error("jpeg: bad segment length");
@@ -184,10 +188,11 @@ raw_image decode_jpeg(const uint8_t* bytes, size_t size) {
                 t.present = true;
                 t.prepare();
             }
-        } else if (marker == 0xC0 || marker == 0xC1) {  // SOF0 / SOF1
+        } else if (marker == 0xC0 || marker == 0xC1 || marker == 0xC2) {  // SOF0 / SOF1 / SOF2
             if (have_frame) throw image_error("jpeg: more than one frame");
             if (n < 6) throw image_error("jpeg: truncated frame header");
             if (seg[0] != 8) throw image_error("jpeg: only 8-bit samples are supported");
+            progressive = marker == 0xC2;
             height = be16(seg + 1); width = be16(seg + 3);
             const int nc = seg[5];
             if (width == 0 || height == 0) throw image_error("jpeg: bad dimensions");
@@ -202,42 +207,158 @@ raw_image decode_jpeg(const uint8_t* bytes, size_t size) {
                 if (comps[c].h > hmax) hmax = comps[c].h;
                 if (comps[c].v > vmax) vmax = comps[c].v;
             }
+            if (nc == 1) { comps[0].h = comps[0].v = 1; hmax = vmax = 1; }  // a single component is never interleaved (T.81 A.2.2)
             for (auto& c : comps) if (hmax % c.h || vmax % c.v) throw image_error("jpeg: fractional sampling ratios are not supported");
+            const int mcu_w = 8 * hmax, mcu_h = 8 * vmax;
+            mcus_x = (width + mcu_w - 1) / mcu_w; mcus_y = (height + mcu_h - 1) / mcu_h;
+            for (auto& c : comps) {
+                c.blocks_w = mcus_x * c.h; c.blocks_h = mcus_y * c.v;
+                c.own_blocks_w = ((width * c.h + hmax - 1) / hmax + 7) / 8;
+                c.own_blocks_h = ((height * c.v + vmax - 1) / vmax + 7) / 8;
+                c.coef.assign((size_t)c.blocks_w * c.blocks_h * 64, 0);
+            }
             have_frame = true;
-        } else if (marker == 0xC2 || marker == 0xC3 || (marker >= 0xC5 && marker <= 0xCF && marker != 0xC8 && marker != 0xCC)) {
-            throw image_error("jpeg: progressive, lossless and arithmetic-coded files are not supported");
+        } else if (marker == 0xC3 || (marker >= 0xC5 && marker <= 0xCF && marker != 0xC8 && marker != 0xCC)) {
+            throw image_error("jpeg: lossless, hierarchical and arithmetic-coded files are not supported");
         } else if (marker == 0xDD) {  // DRI
             if (n < 2) throw image_error("jpeg: bad restart interval");
             restart_interval = be16(seg);
         } else if (marker == 0xEE) {  // APP14 "Adobe"
             if (n >= 12 && std::memcmp(seg, "Adobe", 5) == 0) adobe_transform = seg[11];
-        } else if (marker == 0xDA) {  // SOS: the one scan of a sequential file holding all components
+        } else if (marker == 0xDA) {  // SOS
             if (!have_frame) throw image_error("jpeg: scan before the frame header");
-            if (n < 1 || seg[0] != comps.size() || n < 1 + 2 * comps.size() + 3) throw image_error("jpeg: a scan must hold every component (non-interleaved scans are not supported)");
-            for (size_t k = 0; k < comps.size(); k++) {
+            if (n < 1) throw image_error("jpeg: truncated scan header");
+            const size_t ns = seg[0];
+            if (ns < 1 || ns > comps.size() || n < 1 + 2 * ns + 3) throw image_error("jpeg: bad scan header");
+            std::vector<component*> in_scan;
+            for (size_t k = 0; k < ns; k++) {
                 const int cid = seg[1 + 2 * k];
                 component* c = nullptr;
                 for (auto& cc : comps) if (cc.id == cid) c = &cc;
                 if (!c) throw image_error("jpeg: scan names an unknown component");
+                for (component* seen : in_scan) if (seen == c) throw image_error("jpeg: scan names a component twice");
                 c->td = seg[2 + 2 * k] >> 4; c->ta = seg[2 + 2 * k] & 15;
-                if (c->td > 3 || c->ta > 3 || !dc[c->td].present || !ac[c->ta].present) throw image_error("jpeg: scan names a missing Huffman table");
-                if (!quant_present[c->tq]) throw image_error("jpeg: missing quantisation table");
+                if (c->td > 3 || c->ta > 3) throw image_error("jpeg: scan names a bad Huffman table");
+                in_scan.push_back(c);
             }
-            const int mcu_w = 8 * hmax, mcu_h = 8 * vmax;
-            const int mcus_x = (width + mcu_w - 1) / mcu_w, mcus_y = (height + mcu_h - 1) / mcu_h;
-            for (auto& c : comps) {
-                c.blocks_w = mcus_x * c.h; c.blocks_h = mcus_y * c.v;
-                c.plane.assign((size_t)c.blocks_w * 8 * c.blocks_h * 8, 0);
-                c.pred = 0;
+            const int ss = seg[1 + 2 * ns], se = seg[2 + 2 * ns], ah = seg[3 + 2 * ns] >> 4, al = seg[3 + 2 * ns] & 15;
+            if (!progressive) {
+                if (ss != 0 || se != 63 || ah != 0 || al != 0) throw image_error("jpeg: a sequential scan codes all 64 coefficients at full precision");
+            } else {
+                if (ss > se || se > 63 || al > 13 || ah > 13 || (ah != 0 && ah != al + 1)) throw image_error("jpeg: bad progressive scan parameters");
+                if (ss == 0 && se != 0) throw image_error("jpeg: a progressive scan codes either the DC or some AC coefficients");
+                if (ss > 0 && ns != 1) throw image_error("jpeg: a progressive AC scan holds one component");
             }
+            const bool needs_dc = ss == 0 && ah == 0, needs_ac = se > 0;
+            for (component* c : in_scan) {
+                if (needs_dc && !dc[c->td].present) throw image_error("jpeg: scan names a missing Huffman table");
+                if (needs_ac && !ac[c->ta].present) throw image_error("jpeg: scan names a missing Huffman table");
+                c->pred = 0;
+            }
+            scan_seen = true;
+
+            // A scan of one component walks that component's own blocks; a scan of several walks the frame's MCUs.
+            const bool interleaved = ns > 1;
+            const int units_x = interleaved ? mcus_x : in_scan[0]->own_blocks_w, units_y = interleaved ? mcus_y : in_scan[0]->own_blocks_h;
             entropy_reader er{ bytes + pos, bytes + size };
             int until_restart = restart_interval;
             int expected_rst = 0;
-            int32_t block[64];
-            for (int my = 0; my < mcus_y; my++)
-                for (int mx = 0; mx < mcus_x; mx++) {
+            int eobrun = 0;
+            const int p1 = 1 << al, m1 = -(1 << al);
+            auto refine_nonzero = [&](int16_t& c) {  // one correction bit for a coefficient that is already non-zero
+                if (er.next_bit() && (c & p1) == 0) c = (int16_t)(c + (c >= 0 ? p1 : m1));
+            };
+            auto decode_block = [&](component& c, int16_t* block) {
+                if (!progressive) {
+                    const int t = decode_symbol(er, dc[c.td]);
+                    if (t > 11) throw image_error("jpeg: bad DC category");
+                    c.pred += extend(er.receive(t), t);
+                    block[0] = (int16_t)c.pred;
+                    for (int k = 1; k < 64;) {
+                        const int rs = decode_symbol(er, ac[c.ta]);
+                        const int r = rs >> 4, sz = rs & 15;
+                        if (sz == 0) {
+                            if (r == 15) { k += 16; continue; }
+                            break;  // end of block
+                        }
+                        k += r;
+                        if (k > 63) throw image_error("jpeg: AC coefficient index out of range");
+                        block[kZigzag[k]] = (int16_t)extend(er.receive(sz), sz);
+                        k++;
+                    }
+                    return;
+                }
+                if (ss == 0) {
+                    if (ah == 0) {  // first DC scan: the difference, scaled by the point transform
+                        const int t = decode_symbol(er, dc[c.td]);
+                        if (t > 11) throw image_error("jpeg: bad DC category");
+                        c.pred += extend(er.receive(t), t);
+                        block[0] = (int16_t)(c.pred * (1 << al));
+                    } else if (er.next_bit()) {  // DC refinement: one more bit
+                        block[0] = (int16_t)(block[0] | p1);
+                    }
+                    return;
+                }
+                if (ah == 0) {  // first AC scan of the band [ss, se]
+                    if (eobrun > 0) { eobrun--; return; }
+                    for (int k = ss; k <= se;) {
+                        const int rs = decode_symbol(er, ac[c.ta]);
+                        const int r = rs >> 4, sz = rs & 15;
+                        if (sz == 0) {
+                            if (r == 15) { k += 16; continue; }
+                            eobrun = (1 << r) - 1;                       // this block and eobrun more end here
+                            if (r) eobrun += er.receive(r);
+                            break;
+                        }
+                        k += r;
+                        if (k > se) throw image_error("jpeg: AC coefficient index out of range");
+                        block[kZigzag[k]] = (int16_t)(extend(er.receive(sz), sz) * (1 << al));
+                        k++;
+                    }
+                    return;
+                }
+                // AC refinement (T.81 G.1.2.3): correction bits for the non-zero history, new +-1 coefficients in between
+                int k = ss;
+                if (eobrun == 0) {
+                    for (; k <= se; k++) {
+                        const int rs = decode_symbol(er, ac[c.ta]);
+                        int r = rs >> 4;
+                        const int sz = rs & 15;
+                        int value = 0;
+                        if (sz == 0) {
+                            if (r < 15) {
+                                eobrun = 1 << r;                        // counts this block too
+                                if (r) eobrun += er.receive(r);
+                                break;
+                            }
+                        } else {
+                            if (sz != 1) throw image_error("jpeg: bad coefficient size in a refinement scan");
+                            value = er.next_bit() ? p1 : m1;
+                        }
+                        while (k <= se) {
+                            int16_t& cf = block[kZigzag[k]];
+                            if (cf != 0) refine_nonzero(cf);
+                            else if (--r < 0) break;
+                            k++;
+                        }
+                        if (value) {
+                            if (k > se) throw image_error("jpeg: AC coefficient index out of range");
+                            block[kZigzag[k]] = (int16_t)value;
+                        }
+                    }
+                }
+                if (eobrun > 0) {
+                    for (; k <= se; k++) {
+                        int16_t& cf = block[kZigzag[k]];
+                        if (cf != 0) refine_nonzero(cf);
+                    }
+                    eobrun--;
+                }
+            };
+            for (int uy = 0; uy < units_y; uy++)
+                for (int ux = 0; ux < units_x; ux++) {
                     if (restart_interval && until_restart == 0) {
-                        // byte-align, expect RSTn, reset predictors
+                        // byte-align, expect RSTn, reset predictors and the end-of-band run
                         er.count = 0;
                         const uint8_t* q = er.p;
                         while (q + 1 < er.end && !(q[0] == 0xFF && q[1] >= 0xD0 && q[1] <= 0xD7)) q++;
@@ -246,37 +367,43 @@ raw_image decode_jpeg(const uint8_t* bytes, size_t size) {
                         expected_rst = (expected_rst + 1) & 7;
                         er.p = q + 2;
                         er.reset();
-                        for (auto& c : comps) c.pred = 0;
+                        for (component* c : in_scan) c->pred = 0;
+                        eobrun = 0;
                         until_restart = restart_interval;
                     }
-                    for (auto& c : comps)
-                        for (int by = 0; by < c.v; by++)
-                            for (int bx = 0; bx < c.h; bx++) {
-                                std::memset(block, 0, sizeof block);
-                                const int t = decode_symbol(er, dc[c.td]);
-                                if (t > 11) throw image_error("jpeg: bad DC category");
-                                c.pred += extend(er.receive(t), t);
-                                block[0] = c.pred * quant[c.tq][0];
-                                for (int k = 1; k < 64;) {
-                                    const int rs = decode_symbol(er, ac[c.ta]);
-                                    const int r = rs >> 4, s = rs & 15;
-                                    if (s == 0) {
-                                        if (r == 15) { k += 16; continue; }
-                                        break;  // end of block
-                                    }
-                                    k += r;
-                                    if (k > 63) throw image_error("jpeg: AC coefficient index out of range");
-                                    block[kZigzag[k]] = extend(er.receive(s), s) * quant[c.tq][kZigzag[k]];
-                                    k++;
-                                }
-                                const size_t stride = (size_t)c.blocks_w * 8;
-                                idct_block(block, c.plane.data() + ((size_t)(my * c.v + by) * 8) * stride + (size_t)(mx * c.h + bx) * 8, stride);
-                            }
+                    if (interleaved) {
+                        for (component* c : in_scan)
+                            for (int by = 0; by < c->v; by++)
+                                for (int bx = 0; bx < c->h; bx++)
+                                    decode_block(*c, c->coef.data() + ((size_t)(uy * c->v + by) * c->blocks_w + (size_t)(ux * c->h + bx)) * 64);
+                    } else {
+                        component* c = in_scan[0];
+                        decode_block(*c, c->coef.data() + ((size_t)uy * c->blocks_w + (size_t)ux) * 64);
+                    }
                     if (restart_interval) until_restart--;
                 }
-            decoded = true;
+            // on to the marker that ends the scan's data: 0xFF followed by neither a stuffed zero, a fill byte nor RSTn
+            const uint8_t* q = er.p;
+            while (q + 1 < er.end && !(q[0] == 0xFF && q[1] != 0x00 && q[1] != 0xFF && !(q[1] >= 0xD0 && q[1] <= 0xD7))) q++;
+            pos = (size_t)(q - bytes);
+            if (q + 1 >= er.end) decoded = true;   // no end-of-image marker: take what the scans gave
         }
         // every other segment (APPn, COM, ...) is skipped
+    }
+
+    // dequantise + inverse DCT, once, over everything the scans delivered
+    for (auto& c : comps) {
+        if (!quant_present[c.tq]) throw image_error("jpeg: missing quantisation table");
+        c.plane.assign((size_t)c.blocks_w * 8 * c.blocks_h * 8, 0);
+        const size_t stride = (size_t)c.blocks_w * 8;
+        int32_t block[64];
+        for (int by = 0; by < c.blocks_h; by++)
+            for (int bx = 0; bx < c.blocks_w; bx++) {
+                const int16_t* cf = c.coef.data() + ((size_t)by * c.blocks_w + bx) * 64;
+                for (int k = 0; k < 64; k++) block[k] = (int32_t)cf[k] * quant[c.tq][k];
+                idct_block(block, c.plane.data() + (size_t)by * 8 * stride + (size_t)bx * 8, stride);
+            }
+        std::vector<int16_t>().swap(c.coef);
     }
 
     raw_image img;

@@ -203,12 +203,59 @@ def test_jpeg_greyscale_and_errors():
     want = np.asarray(Image.open(io.BytesIO(buf.getvalue()))).astype(np.int32)
     assert channels == 1 and np.abs(got[..., 0].astype(np.int32) - want).max() <= 2
     assert np.array_equal(got[..., 0], got[..., 1]) and np.array_equal(got[..., 0], got[..., 2])
-    prog = io.BytesIO()
-    Image.fromarray(smooth_image(32, 32, 1)).save(prog, format="JPEG", progressive=True)
-    with pytest.raises(host.HostError, match="progressive"):
-        host.image_decode(prog.getvalue())
     with pytest.raises(host.HostError):
         host.image_decode(buf.getvalue()[:200])
+
+
+@pytest.mark.parametrize("subsampling,quality,size,mode,restart", [(0, 95, (40, 56), "RGB", 0), (2, 90, (67, 45), "RGB", 0), (1, 80, (41, 59), "RGB", 0),
+                                                                   (2, 92, (64, 64), "RGB", 3), (0, 90, (33, 47), "L", 0), (2, 30, (96, 80), "RGB", 0),
+                                                                   (0, 100, (24, 24), "RGB", 0)])
+def test_progressive_jpeg_matches_pillow_within_decoder_tolerance(subsampling, quality, size, mode, restart):
+    """Progressive files (spectral selection + successive approximation, DC and AC refinement scans, end-of-band runs):
+    the coefficients must come out exactly as libjpeg's, so the tolerance is the sequential one."""
+    Image = pytest.importorskip("PIL.Image")
+    img = smooth_image(size[0], size[1], subsampling + quality)
+    if mode == "L":
+        img = img[..., 0]
+    buf = io.BytesIO()
+    kw = dict(restart_marker_blocks=restart) if restart else {}
+    if mode == "RGB":
+        kw["subsampling"] = subsampling
+    Image.fromarray(img, mode).save(buf, format="JPEG", quality=quality, progressive=True, **kw)
+    data = buf.getvalue()
+    assert b"\xff\xc2" in data, "a progressive frame header"
+    assert data.count(b"\xff\xda") > 3, "several scans"
+    got, channels = host.image_decode(data)
+    want = np.asarray(Image.open(io.BytesIO(data)).convert("RGB")).astype(np.int32)
+    assert channels == (3 if mode == "RGB" else 1) and got.shape == (size[0], size[1], 4)
+    diff = np.abs(got[..., :3].astype(np.int32) - want)
+    assert diff.mean() < (0.1 if subsampling == 0 or mode == "L" else 0.6), diff.mean()
+    assert diff.max() <= 3, diff.max()
+    # and the same picture coded sequentially decodes to the same samples up to the coder's own choice of tables
+    seq = io.BytesIO()
+    Image.fromarray(img, mode).save(seq, format="JPEG", quality=quality, **kw)
+    got_seq, _ = host.image_decode(seq.getvalue())
+    assert np.array_equal(got, got_seq), "progressive and sequential codings of the same coefficients decode alike"
+
+
+def test_progressive_jpeg_cut_after_its_first_scan():
+    """Only the first scan (DC of all components) followed by the end marker: a blocky but valid picture, as the format
+    intends for partial transmissions.  (The later scans of a progressive file each hold ONE component: the per-component
+    scan walk is what the test above exercises.)"""
+    Image = pytest.importorskip("PIL.Image")
+    img = smooth_image(37, 53, 9)
+    prog = io.BytesIO()
+    Image.fromarray(img).save(prog, format="JPEG", quality=90, subsampling=2, progressive=True)
+    p = prog.getvalue()
+    first_scan = p.index(b"\xff\xda")
+    second_scan = p.index(b"\xff\xda", first_scan + 2)
+    tables = p.rfind(b"\xff\xc4", first_scan, second_scan)     # the Huffman tables sent ahead of the second scan
+    cut = p[:tables if tables > first_scan else second_scan] + b"\xff\xd9"
+    got, _ = host.image_decode(cut)
+    want = np.asarray(Image.open(io.BytesIO(p)).convert("RGB")).astype(np.int32)
+    assert got.shape == (37, 53, 4)
+    err = np.abs(got[..., :3].astype(np.int32) - want).mean()
+    assert 1.0 < err < 40.0, err
 
 
 # ---- glTF -> flat arrays -----------------------------------------------------------------------------------------

@@ -30,7 +30,9 @@ def test_corrupted_files_never_crash_the_readers(tmp_path):
     try:
         from PIL import Image
         img = rng.integers(0, 256, (40, 48, 3)).astype(np.uint8)
-        for name, kw in (("a.jpg", dict(quality=90, subsampling=2)), ("b.jpg", dict(quality=75, subsampling=0, restart_marker_blocks=2))):
+        for name, kw in (("a.jpg", dict(quality=90, subsampling=2)), ("b.jpg", dict(quality=75, subsampling=0, restart_marker_blocks=2)),
+                         ("progressive.jpg", dict(quality=85, subsampling=2, progressive=True)),
+                         ("progressive_restarts.jpg", dict(quality=60, subsampling=1, progressive=True, restart_marker_blocks=3))):
             buf = io.BytesIO()
             Image.fromarray(img).save(buf, format="JPEG", **kw)
             put(name, buf.getvalue())
