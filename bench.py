@@ -218,6 +218,8 @@ def main():
     stream = torch.cuda.Stream()
     with torch.cuda.stream(stream):
         ctx = hip.Context(local_rank, stream=stream.cuda_stream if args.stream == "torch" else None)
+        for kv in filter(None, os.environ.get("PTR_BENCH_OPTIONS", "").split(",")):   # tuning experiments: "key=value,key=value"
+            ctx.set_option(kv.split("=")[0], int(kv.split("=")[1]))
         gpu = hip.GpuScene(ctx, sc, nodes, flat, meta)
         if args.bvh == "gpu":
             gpu.wire(ctx.create_compute_renderpass())          # the context's index layout for this scene

@@ -92,6 +92,7 @@ struct ptr_ctx {
     int opt_frames_in_flight = 2;   // 1 = every frame start to end on the context's stream
     int cu_count = 256;
     int opt_extend_inner_reps = 3;  // inner-node steps per inner turn
+    int opt_build_traversal_cost = 100;  // GPU tree build: cost of entering a node, in percent of one triangle test
     int opt_extend_leaf_all = 1;    // 1: a leaf turn tests every triangle of the leaf, 0: one triangle per turn
     int opt_extend_leaf_weight = 2; // leaf lanes count this many times when a traversal wave picks its next step kind
     int opt_extend_refill = 16;     // idle lanes that trigger a refill of the traversal wave (8, 16, 32, 48, 64)
@@ -933,7 +934,7 @@ int ptr_bvh_build_flat(ptr_ctx* c, ptr_handle indices, ptr_handle positions, uin
     int status = 0;
     hipEvent_t t0 = nullptr, t1 = nullptr;
     if (c->profile_on) { t0 = take_event(c); t1 = take_event(c); if (t0) (void)hipEventRecord(t0, c->stream); }
-    const hipError_t e = ptr::build_flat_bvh(c->stream, sv, triangle_count, (uint32_t)(vertices > 0xffffffffull ? 0xffffffffull : vertices), b.ptr, bytes, &status);
+    const hipError_t e = ptr::build_flat_bvh(c->stream, sv, triangle_count, (uint32_t)(vertices > 0xffffffffull ? 0xffffffffull : vertices), b.ptr, bytes, (float)c->opt_build_traversal_cost * 0.01f, &status);
     if (c->profile_on && t0 && t1) { (void)hipEventRecord(t1, c->stream); c->profile["bvh.build_flat"].pending.emplace_back(t0, t1); }
     if (e != hipSuccess || status != 0) {
         (void)hipFree(b.ptr);
@@ -1007,6 +1008,11 @@ int ptr_set_option(ptr_ctx* c, const char* key, int value) {
     if (!strcmp(key, "extend.leaf_weight")) {
         if (value != 1 && value != 2 && value != 4) return fail(c, PTR_E_INVALID, "extend.leaf_weight: 1, 2 or 4");
         c->opt_extend_leaf_weight = value;
+        return PTR_OK;
+    }
+    if (!strcmp(key, "build.traversal_cost")) {
+        if (value < 0 || value > 10000) return fail(c, PTR_E_INVALID, "build.traversal_cost: 0..10000 (percent of a triangle test)");
+        c->opt_build_traversal_cost = value;
         return PTR_OK;
     }
     if (!strcmp(key, "extend.inner_reps")) {

@@ -77,7 +77,8 @@ hipError_t launch_wf_accumulate(hipStream_t s, const SceneView& sv, const Wavefr
 // (flat_build_blob_bytes(n) bytes of device memory).  Synchronous.  *status: 0 ok, < 0 = why the tree could not be built
 // (-1 bad arguments, -3 node capacity or quantisation, -5 deeper than the traversal stack, others internal).
 size_t flat_build_blob_bytes(uint32_t triangle_count);
-hipError_t build_flat_bvh(hipStream_t s, const SceneView& sv, uint32_t triangle_count, uint32_t vertex_count, void* blob, size_t blob_bytes, int* status);
+// traversal_cost: cost of entering a node relative to one triangle test, for the leaf decision (surface-area heuristic).
+hipError_t build_flat_bvh(hipStream_t s, const SceneView& sv, uint32_t triangle_count, uint32_t vertex_count, void* blob, size_t blob_bytes, float traversal_cost, int* status);
 
 // Contents check of the buffers a "compute" dispatch dereferences (ptr_kernels_validate.hip).  out4 (device, 4 words):
 // max vertex id, max material id, violations in the threaded nodes, violations in the flattened layout (and in the top

@@ -7,8 +7,9 @@
 //   2. 63-bit Morton key of the centroid (21 bits per axis), radix sort of (key, triangle) pairs (hipCUB)
 //   3. binary radix tree over the sorted keys, ties broken by position; parents recorded
 //   4. boxes bottom-up: the second thread to reach a node merges its children and goes on
-//   5. leaves: subtrees of at most 4 triangles (contiguous in sorted order, so triangle records are simply written
-//      in sorted order); wide nodes level by level from the root: a node adopts its two children and keeps replacing
+//   5. leaves: a subtree of at most 4 triangles becomes one leaf when that is cheaper, by the surface-area heuristic,
+//      than entering its two children (evaluated bottom-up together with the boxes; the triangles of a subtree are
+//      contiguous in sorted order, so triangle records are simply written in sorted order); wide nodes level by level from the root: a node adopts its two children and keeps replacing
 //      the inner child of largest surface area by that child's children until it has four
 #pragma clang fp contract(off)
 
@@ -29,6 +30,8 @@ struct BuildNode {      // one internal node of the binary radix tree
     int32_t left, right;       // >= 0: internal node, < 0: ~sorted position of a single triangle
     uint32_t first, last;      // range of sorted positions covered
     float lo[3], hi[3];
+    float cost;                // surface-area cost of the cheapest way to finish this subtree (a leaf, or its two children)
+    uint32_t leaf;             // 1: the subtree becomes one leaf
 };
 
 struct Frontier { uint32_t node, wide, pending; };
@@ -135,7 +138,7 @@ __global__ __launch_bounds__(256) void build_tree(uint32_t n, const uint64_t* ke
 // ---- 4. boxes bottom-up + triangle records (written in sorted order) ---------------------------------------
 __global__ __launch_bounds__(256) void build_fit(SceneView sv, uint32_t n, uint32_t vertex_count, const uint32_t* vals, const float4* box_lo,
                                                  const float4* box_hi, BuildNode* nodes, const int32_t* node_parent, const int32_t* leaf_parent,
-                                                 uint32_t* visits, float4* out_tris) {
+                                                 uint32_t* visits, float4* out_tris, float traversal_cost) {
     const uint32_t p = blockIdx.x * 256u + threadIdx.x;
     if (p >= n) return;
     const uint32_t tri = vals[p];
@@ -158,9 +161,11 @@ __global__ __launch_bounds__(256) void build_fit(SceneView sv, uint32_t n, uint3
         __threadfence();
         BuildNode& nd = nodes[node];
         float lo[3], hi[3];
+        float children_cost = 0.f;   // sum over the two children of area * cost
         for (int side = 0; side < 2; side++) {
             const int32_t c = side ? nd.right : nd.left;
             float clo[3], chi[3];
+            float ccost = 1.f;       // one triangle test
             if (c < 0) {
                 const uint32_t t = vals[(uint32_t)~c];
                 const float4 l4 = box_lo[t], h4 = box_hi[t];
@@ -168,13 +173,25 @@ __global__ __launch_bounds__(256) void build_fit(SceneView sv, uint32_t n, uint3
             } else {
                 const volatile BuildNode& cn = nodes[c];
                 for (int a = 0; a < 3; a++) { clo[a] = cn.lo[a]; chi[a] = cn.hi[a]; }
+                ccost = cn.cost;
             }
+            const float dx = chi[0] - clo[0], dy = chi[1] - clo[1], dz = chi[2] - clo[2];
+            children_cost += (dx * dy + dy * dz + dz * dx) * ccost;
             for (int a = 0; a < 3; a++) {
                 lo[a] = side ? min_num(lo[a], clo[a]) : clo[a];
                 hi[a] = side ? max_num(hi[a], chi[a]) : chi[a];
             }
         }
         for (int a = 0; a < 3; a++) { nd.lo[a] = lo[a]; nd.hi[a] = hi[a]; }
+        {
+            const float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+            const float area = dx * dy + dy * dz + dz * dx;
+            const uint32_t count = nd.last - nd.first + 1u;
+            const float split_cost = area > 0.f ? traversal_cost + children_cost / area : __builtin_inff();
+            const bool leaf = count <= kLeafMax && !(split_cost < (float)count);
+            nd.cost = leaf ? (float)count : split_cost;
+            nd.leaf = leaf ? 1u : 0u;
+        }
         node = node_parent[node];
     }
 }
@@ -227,7 +244,7 @@ __global__ __launch_bounds__(128) void build_collapse(uint32_t count, const Fron
     const uint32_t f = blockIdx.x * 128u + threadIdx.x;
     if (f >= count) return;
     const Frontier item = in[f];
-    auto is_inner = [&](int32_t c) { return c >= 0 && nodes[c].last - nodes[c].first + 1u > kLeafMax; };
+    auto is_inner = [&](int32_t c) { return c >= 0 && nodes[c].leaf == 0u; };
     auto box_of = [&](int32_t c, ChildBox& b) {
         if (c < 0) {
             const uint32_t t = vals[(uint32_t)~c];
@@ -308,7 +325,7 @@ size_t flat_build_blob_bytes(uint32_t triangle_count) {
     return 64 + (size_t)triangle_count * 64 + (size_t)triangle_count * 64;
 }
 
-hipError_t build_flat_bvh(hipStream_t s, const SceneView& sv, uint32_t n, uint32_t vertex_count, void* blob, size_t blob_bytes, int* status) {
+hipError_t build_flat_bvh(hipStream_t s, const SceneView& sv, uint32_t n, uint32_t vertex_count, void* blob, size_t blob_bytes, float traversal_cost, int* status) {
     *status = 0;
     if (n == 0 || vertex_count == 0 || blob_bytes < flat_build_blob_bytes(n)) { *status = -1; return hipSuccess; }
     const uint32_t node_capacity = n;
@@ -355,7 +372,7 @@ hipError_t build_flat_bvh(hipStream_t s, const SceneView& sv, uint32_t n, uint32
     float4* out_nodes = (float4*)(out + 64);
     float4* out_tris = (float4*)(out + 64 + (size_t)node_capacity * 64);
     if (n > 1) hipLaunchKernelGGL(build_tree, dim3((n - 1 + 255u) / 256u), dim3(256), 0, s, n, keys_sorted, nodes, node_parent, leaf_parent);
-    hipLaunchKernelGGL(build_fit, dim3(blocks), dim3(256), 0, s, sv, n, vertex_count, vals_sorted, box_lo, box_hi, nodes, node_parent, leaf_parent, visits, out_tris);
+    hipLaunchKernelGGL(build_fit, dim3(blocks), dim3(256), 0, s, sv, n, vertex_count, vals_sorted, box_lo, box_hi, nodes, node_parent, leaf_parent, visits, out_tris, traversal_cost);
     BUILD_CHECK(hipGetLastError());
 
     FlatHeader hd{};
