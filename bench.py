@@ -299,7 +299,7 @@ def main():
         loop.reset()
         ctx.set_option("frames.in_flight", 1)
         ctx.profile_enable(True)
-        solo_frames = min(args.steps, 10)
+        solo_frames = args.steps              # the same sample indices as the timed frames: a frame's cost depends on its sample index
         for _ in range(solo_frames):
             loop.frame()
         torch.cuda.synchronize()

@@ -121,6 +121,8 @@ int ptr_set_sample_partition(ptr_ctx* ctx, uint32_t rank, uint32_t world);
  *      "extend.refill"         idle lanes at which a persistent traversal wave fetches new rays: 8, 16 (default),
  *                              32 or 64 (64 = only when the whole wave is idle)
  *      "extend.inner_reps"     1..3 inner-node steps per inner turn of a traversal wave
+ *      "extend.alone_turns"    iterations the last ray of a traversal wave walks alone (nothing left to fetch) before all 64
+ *                              lanes finish it together, one pending node or leaf per lane (default 0; 1000000 = never)
  *      "build.traversal_cost"  ptr_bvh_build_flat: cost of entering a node in percent of one triangle test (default 100); a
  *                              subtree of up to 4 triangles becomes one leaf when that is cheaper by the surface-area heuristic
  *      "extend.leaf_all"       1 (default): a leaf turn tests the lane's whole leaf; 0: one triangle per turn

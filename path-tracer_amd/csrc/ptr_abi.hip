@@ -92,6 +92,7 @@ struct ptr_ctx {
     int opt_frames_in_flight = 2;   // 1 = every frame start to end on the context's stream
     int cu_count = 256;
     int opt_extend_inner_reps = 3;  // inner-node steps per inner turn
+    int opt_extend_alone_turns = 0;  // turns a wave's last ray walks alone before the wave finishes it together
     int opt_build_traversal_cost = 100;  // GPU tree build: cost of entering a node, in percent of one triangle test
     int opt_extend_leaf_all = 1;    // 1: a leaf turn tests every triangle of the leaf, 0: one triangle per turn
     int opt_extend_leaf_weight = 2; // leaf lanes count this many times when a traversal wave picks its next step kind
@@ -541,6 +542,7 @@ int dispatch_compute(ptr_ctx* c, const uint8_t constants[64], uint32_t gx, uint3
     // queue slots: whole 8x8 tiles of the owned rows (padded by one stripe); samples are indexed by pixel
     const uint32_t padded = ((meta.width + 7u) / 8u) * ((meta.height + 7u) / 8u + c->part_stripe / 8u) * 64u;
     if ((rc = ensure_scratch(c, slot, padded > meta.width * meta.height ? padded : meta.width * meta.height, fv.max_depth))) return rc;
+    slot.scratch.alone_turns = (uint32_t)c->opt_extend_alone_turns;
     const ptr::WavefrontScratch& w = slot.scratch;
 
     if (overlap) {
@@ -1008,6 +1010,11 @@ int ptr_set_option(ptr_ctx* c, const char* key, int value) {
     if (!strcmp(key, "extend.leaf_weight")) {
         if (value != 1 && value != 2 && value != 4) return fail(c, PTR_E_INVALID, "extend.leaf_weight: 1, 2 or 4");
         c->opt_extend_leaf_weight = value;
+        return PTR_OK;
+    }
+    if (!strcmp(key, "extend.alone_turns")) {
+        if (value < 0 || value > 1000000) return fail(c, PTR_E_INVALID, "extend.alone_turns: 0..1000000");
+        c->opt_extend_alone_turns = value;
         return PTR_OK;
     }
     if (!strcmp(key, "build.traversal_cost")) {

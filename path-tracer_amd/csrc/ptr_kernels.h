@@ -44,6 +44,7 @@ struct WavefrontScratch {
     uint32_t capacity;
     uint32_t extend_blocks; // persistent grid size
     uint32_t spill_entries; // per-lane entries of stack_spill (sized for the deepest tree bound so far)
+    uint32_t alone_turns;   // turns a traversal wave's last ray walks alone before all 64 lanes take it over
 };
 
 constexpr uint32_t kMaxBounceSlots = 16;   // counters per array; deeper paths reuse the slots cyclically

@@ -70,15 +70,10 @@ __global__ __launch_bounds__(256) void build_boxes(SceneView sv, uint32_t n, uin
 }
 
 // ---- 2. Morton keys ----------------------------------------------------------------------------------------
-PTR_DEV uint64_t spread21(uint32_t v) {  // 21 bits -> every third bit of 63
-    uint64_t x = v & 0x1fffffu;
-    x = (x | (x << 32)) & 0x1f00000000ffffull;
-    x = (x | (x << 16)) & 0x1f0000ff0000ffull;
-    x = (x | (x << 8)) & 0x100f00f00f00f00full;
-    x = (x | (x << 4)) & 0x10c30c30c30c30c3ull;
-    x = (x | (x << 2)) & 0x1249249249249249ull;
-    return x;
-}
+// 63 key bits, handed out from the top: each bit halves the axis along which the cells are currently longest, so the
+// cells stay as close to cubes as the scene box allows (plain x, y, z interleaving halves a flat scene's short axis as
+// often as its long ones, and every such split leaves both children with nearly the parent's surface area).
+// An axis contributes at most 24 bits, what an fp32 coordinate resolves.
 __global__ __launch_bounds__(256) void build_keys(uint32_t n, const float4* box_lo, const float4* box_hi, const uint32_t* scene, uint64_t* keys, uint32_t* vals) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i >= n) return;
@@ -87,14 +82,26 @@ __global__ __launch_bounds__(256) void build_keys(uint32_t n, const float4* box_
     const float smax[3] = { unordered(scene[3]), unordered(scene[4]), unordered(scene[5]) };
     const float c[3] = { 0.5f * lo.x + 0.5f * hi.x, 0.5f * lo.y + 0.5f * hi.y, 0.5f * lo.z + 0.5f * hi.z };
     uint32_t q[3];
+    float cell[3];
     for (int a = 0; a < 3; a++) {
         const float extent = smax[a] - smin[a];
         float t = extent > 0.f ? (c[a] - smin[a]) / extent : 0.f;
         t = t >= 0.f ? t : 0.f;                       // also catches NaN
-        const float s = t * 2097152.0f;
-        q[a] = s >= 2097151.0f ? 2097151u : (uint32_t)s;
+        const float s = t * 16777216.0f;
+        q[a] = s >= 16777215.0f ? 16777215u : (uint32_t)s;
+        cell[a] = extent > 0.f ? extent : 0.f;
     }
-    keys[i] = (spread21(q[0]) << 2) | (spread21(q[1]) << 1) | spread21(q[2]);
+    uint32_t used[3] = { 0u, 0u, 0u };
+    uint64_t key = 0;
+    for (int k = 0; k < 63; k++) {
+        int a = -1;
+        for (int j = 0; j < 3; j++)
+            if (used[j] < 24u && (a < 0 || cell[j] > cell[a])) a = j;
+        key = (key << 1) | (uint64_t)((q[a] >> (23u - used[a])) & 1u);
+        used[a]++;
+        cell[a] *= 0.5f;
+    }
+    keys[i] = key;
     vals[i] = i;
 }
 

@@ -159,6 +159,8 @@ __global__ __launch_bounds__(kExtendThreads, 4) void ptr_wf_extend(FlatView fv, 
     int32_t cur_inst = -1, best_inst = -1;       // TWO_LEVEL: the copy the lane is inside (-1: top level), the copy of the best hit
     int32_t cur = kTraversalDone;
     uint32_t sp = 0u;
+    uint32_t alone_turns = 0u;                  // wave-uniform: iterations with a single busy lane and nothing left to fetch
+    int lone_lane = -1;
 
     for (;;) {
         const unsigned long long idle = __ballot(slot == kInvalidPixel);
@@ -187,6 +189,10 @@ __global__ __launch_bounds__(kExtendThreads, 4) void ptr_wf_extend(FlatView fv, 
             continue;  // re-evaluate: skipped entries leave lanes idle
         }
         if (idle == ~0ull) break;  // nothing in flight and my list is exhausted
+        if (!STATS && !TWO_LEVEL && next_k >= my_rays && __popcll(~idle) == 1) {
+            // one ray left in the wave and nothing to fetch: after a while the whole wave finishes it together (below)
+            if (++alone_turns > w.alone_turns) { lone_lane = (int)__ffsll((long long)~idle) - 1; break; }
+        }
 
         const bool at_inner = slot != kInvalidPixel && cur >= 0;
         const bool at_leaf = slot != kInvalidPixel && cur < 0;
@@ -322,6 +328,133 @@ __global__ __launch_bounds__(kExtendThreads, 4) void ptr_wf_extend(FlatView fv, 
             if (TWO_LEVEL) w.hit_instance[slot] = best_inst;
             slot = kInvalidPixel;
         }
+    }
+
+    // ---- the wave's last ray, finished by all 64 lanes -------------------------------------------------------------
+    // A lone lane pays a full memory latency per node; rays that graze a long run of boxes (thousands of nodes) would
+    // hold the whole launch for milliseconds.  Its pending references (stack + current) become one list in the wave's
+    // LDS; every turn up to 64 of them are popped, one per lane: a node lane tests its four children and appends the
+    // ones the ray enters, a leaf lane tests its triangles.  Candidates are reduced with the rule of the sequential
+    // walk (smaller t, on equal t the later rank), which does not depend on the visiting order, so the hit is the same.
+    if (!STATS && !TWO_LEVEL && lone_lane >= 0) {
+        int32_t* list = lds_stack + wave_in_block * kStackLds * 64;   // kStackLds * 64 entries, linear
+        constexpr uint32_t kListMax = kStackLds * 64;
+        constexpr uint32_t kWideLimit = kListMax - kStackMax - 8u;    // above this only the top entry is popped (depth-first: bounded growth)
+        const int L = lone_lane;
+        const f3 ro = mk3(__shfl(o.x, L), __shfl(o.y, L), __shfl(o.z, L));
+        const f3 rd = mk3(__shfl(d.x, L), __shfl(d.y, L), __shfl(d.z, L));
+        const f3 rinv = mk3(rcp(rd.x), rcp(rd.y), rcp(rd.z));
+        const bool ngx = (as_u32(rinv.x) >> 31) != 0u, ngy = (as_u32(rinv.y) >> 31) != 0u, ngz = (as_u32(rinv.z) >> 31) != 0u;
+        float bt = __shfl(best_t, L), bu = __shfl(best_u, L), bv = __shfl(best_v, L);
+        int32_t brank = __shfl(best_rank, L), bprim = __shfl(best_prim, L);
+        const uint32_t the_slot = __shfl(slot, L);
+        const uint32_t depth = __shfl(sp, L);
+        const int32_t top = __shfl(cur, L);
+        // gather the lane-interleaved stack of lane L, then lay it out linearly (at most kStackMax + 3 entries: four per lane)
+        const int32_t* spill_of_l = my_spill - lane + L;
+        int32_t held[4];
+        #pragma unroll
+        for (uint32_t j = 0; j < 4u; j++) {
+            const uint32_t e = lane + 64u * j;
+            held[j] = 0;
+            if (e < depth) held[j] = e < kStackLds ? list[e * 64u + (uint32_t)L] : spill_of_l[(e - kStackLds) * 64u];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        #pragma unroll
+        for (uint32_t j = 0; j < 4u; j++) {
+            const uint32_t e = lane + 64u * j;
+            if (e < depth && e < kListMax) list[e] = held[j];
+        }
+        uint32_t size = depth < kListMax ? depth : kListMax;
+        if (lane == 0u && top != kTraversalDone && size < kListMax) list[size] = top;
+        if (top != kTraversalDone) size++;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+
+        while (size > 0u) {
+            uint32_t pops = size < 64u ? size : 64u;
+            if (size + 3u * pops > kWideLimit) pops = size >= kWideLimit ? 1u : (kWideLimit - size) / 3u;
+            if (pops == 0u) pops = 1u;
+            const bool mine = lane < pops;
+            const int32_t ref = mine ? list[size - 1u - lane] : kEmptyChild;
+            size -= pops;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+
+            int32_t r0 = kEmptyChild, r1 = kEmptyChild, r2 = kEmptyChild, r3 = kEmptyChild;
+            uint32_t n_push = 0u;
+            float ct = __builtin_inff(), cu = 0.0f, cv = 0.0f;   // this lane's candidate hit
+            int32_t crank = -1, cprim = -1;
+            if (mine && ref >= 0) {
+                const float4 q0 = fv.nodes[4 * ref];
+                const int4 refs = ((const int4*)fv.nodes)[4 * ref + 1];
+                const uint4 qa = ((const uint4*)fv.nodes)[4 * ref + 2];
+                const uint4 qb = ((const uint4*)fv.nodes)[4 * ref + 3];
+                const f3 A = mk3(q0.w * rinv.x, __uint_as_float(qb.z) * rinv.y, __uint_as_float(qb.w) * rinv.z);
+                const f3 B = mk3((q0.x - ro.x) * rinv.x, (q0.y - ro.y) * rinv.y, (q0.z - ro.z) * rinv.z);
+                const uint32_t near_x = ngx ? qa.w : qa.x, far_x = ngx ? qa.x : qa.w;
+                const uint32_t near_y = ngy ? qb.x : qa.y, far_y = ngy ? qa.y : qb.x;
+                const uint32_t near_z = ngz ? qb.y : qa.z, far_z = ngz ? qa.z : qb.y;
+                r0 = refs.x; r1 = refs.y; r2 = refs.z; r3 = refs.w;
+                const float inf = __builtin_inff();
+                float k0, k1, k2, k3;
+                child_entries(near_x, near_y, near_z, far_x, far_y, far_z, A, B, min_t, bt, k0, k1, k2, k3);
+                if (r2 == kEmptyChild) k2 = inf;
+                if (r3 == kEmptyChild) k3 = inf;
+                sort_pair(k0, r0, k1, r1);
+                sort_pair(k2, r2, k3, r3);
+                sort_pair(k0, r0, k2, r2);
+                sort_pair(k1, r1, k3, r3);
+                sort_pair(k1, r1, k2, r2);
+                n_push = (k0 < inf ? 1u : 0u) + (k1 < inf ? 1u : 0u) + (k2 < inf ? 1u : 0u) + (k3 < inf ? 1u : 0u);  // hits are sorted to the front
+            } else if (mine && ref != kEmptyChild) {
+                uint32_t lr = (uint32_t)~ref;
+                for (;;) {
+                    const uint32_t first = lr >> 2, remaining = lr & 3u;
+                    const float4* tr = fv.triangles + 4 * (size_t)first;
+                    const float4 a = tr[0], b = tr[1], c = tr[2], n4 = tr[3];
+                    const f3 e1 = mk3(b.x, b.y, b.z), e2 = mk3(c.x, c.y, c.z), n = mk3(n4.x, n4.y, n4.z);
+                    const f3 ov = ro - mk3(a.x, a.y, a.z);
+                    const f3 q = cross(ov, rd);
+                    const float dd = rcp(dot(rd, n));
+                    const float u = dd * dot(-q, e2);
+                    const float v = dd * dot(q, e1);
+                    const float t = dd * dot(-n, ov);
+                    const bool reject = u < 0.0f || u > 1.0f || v < 0.0f || u + v > 1.0f || t < min_t || t > bt || t != t || u != u || v != v;
+                    const int32_t rank = __float_as_int(a.w);
+                    if (!reject && (t < ct || (t == ct && rank > crank))) { ct = t; cu = u; cv = v; crank = rank; cprim = __float_as_int(b.w); }
+                    if (remaining == 0u) break;
+                    lr = ((first + 1u) << 2) | (remaining - 1u);
+                }
+            }
+            // the best candidate of the turn: smallest t, then the later rank
+            if (__ballot(cprim >= 0) != 0ull) {
+                #pragma unroll
+                for (int off = 32; off > 0; off >>= 1) {
+                    const float ot = __shfl_xor(ct, off), ou = __shfl_xor(cu, off), ov2 = __shfl_xor(cv, off);
+                    const int32_t orank = __shfl_xor(crank, off), oprim = __shfl_xor(cprim, off);
+                    const bool take = oprim >= 0 && (cprim < 0 || ot < ct || (ot == ct && orank > crank));
+                    if (take) { ct = ot; cu = ou; cv = ov2; crank = orank; cprim = oprim; }
+                }
+                if (cprim >= 0 && !(bprim >= 0 && ct == bt && crank < brank)) { bt = ct; bu = cu; bv = cv; brank = crank; bprim = cprim; }
+            }
+            // append the entered children: farthest first within a lane, so that a depth-first turn pops the nearest
+            const unsigned long long b0 = __ballot((n_push & 1u) != 0u), b1 = __ballot((n_push & 2u) != 0u), b2 = __ballot((n_push & 4u) != 0u);
+            const unsigned long long below = (1ull << lane) - 1ull;
+            const uint32_t offset = (uint32_t)__popcll(b0 & below) + 2u * (uint32_t)__popcll(b1 & below) + 4u * (uint32_t)__popcll(b2 & below);
+            const uint32_t total = (uint32_t)__popcll(b0) + 2u * (uint32_t)__popcll(b1) + 4u * (uint32_t)__popcll(b2);
+            if (size + total > kListMax) break;   // cannot happen while the header's stack bound holds; never write past the list
+            uint32_t at = size + offset;
+            if (n_push > 3u) list[at++] = r3;
+            if (n_push > 2u) list[at++] = r2;
+            if (n_push > 1u) list[at++] = r1;
+            if (n_push > 0u) list[at++] = r0;
+            size += total;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (lane == 0u) w.hits[the_slot] = make_float4(bt, bu, bv, __int_as_float(bprim));
     }
     if (STATS && stats) {
         for (int off = 32; off > 0; off >>= 1) {

@@ -26,6 +26,9 @@ def main():
     ap.add_argument("--bounces", type=int, default=4)
     ap.add_argument("--texture-size", type=int, default=512)
     ap.add_argument("--pipeline", default="compute")
+    ap.add_argument("--instances", default="1x1")
+    ap.add_argument("--two-level", action="store_true")
+    ap.add_argument("--bvh", default="host", choices=["host", "gpu"])
     ap.add_argument("--no-profile", action="store_true", help="time whole frames only (no events between kernels)")
     args = ap.parse_args()
     import bench
@@ -40,6 +43,9 @@ def main():
     sc, nodes, flat, meta, _ = bench.build_scene(args, 0)
     ctx = hip.Context(0)
     gpu = hip.GpuScene(ctx, sc, nodes, flat, meta)
+    if args.bvh == "gpu":
+        gpu.wire(ctx.create_compute_renderpass())
+        ctx.bind_flat(gpu.bvh_buffer, ctx.build_flat(gpu.indices_buffer, gpu.positions_buffer, sc["triangles"].shape[0]))
     textures = None
     if os.environ.get("PTR_AB_TORCH") == "wrap":  # the two images live in torch tensors, as in bench.py
         ia = torch.zeros((args.height, args.width, 4), dtype=torch.float32, device="cuda")

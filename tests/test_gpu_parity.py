@@ -354,6 +354,27 @@ def test_dispatch_smaller_and_larger_than_the_image(ctx):
             assert (img[~covered] == 0).all(), (pipeline, gx, gy)
 
 
+@pytest.mark.parametrize("turns", [0, 3, 1000000])
+@pytest.mark.parametrize("kind,target,w,h,bounces", [("tiny", 0, 64, 40, 6), ("atrium", 5000, 160, 90, 4)])
+def test_last_ray_of_a_wave_finished_by_all_lanes(ctx, turns, kind, target, w, h, bounces):
+    """extend.alone_turns: when a traversal wave is down to one ray, all 64 lanes take its pending nodes and leaves, in
+    another order than the single lane would -- the closest hit (ties by rank) does not depend on the order.  0 hands
+    every wave's last ray over at once, 1000000 never does."""
+    b = make_bundle(kind, target, w, h, max_bounce=bounces)
+    ctx.set_option("extend.alone_turns", turns)
+    try:
+        img, gs, cap, _ = gpu_frames(ctx, b, 3, "compute.wavefront", capture=True)
+        img2, _, _, _ = gpu_frames(ctx, b, 4, "compute.wavefront", gpu_scene=gs)      # two frames in flight (no capture)
+    finally:
+        ctx.set_option("extend.alone_turns", 0)
+    ref, _, aov = oracle_for(b, gs, 3, use_flat=True, aov=True)
+    assert_same(cap[0], aov[0], "primitive ids")
+    assert_same(cap[1], aov[1], "hit distances")
+    assert_same(img, ref, f"image, alone_turns {turns}")
+    ref2, _, _ = oracle_for(b, gs, 4, use_flat=True)
+    assert_same(img2, ref2, f"image of the overlapped frames, alone_turns {turns}")
+
+
 def test_debug_bvh_heatmap(ctx):
     b = make_bundle("atrium", 3000, 64, 40, debug_bvh=1)
     img, gs, _, _ = gpu_frames(ctx, b, 1, "compute.megakernel")
