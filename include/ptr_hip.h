@@ -128,7 +128,7 @@ int ptr_set_sample_partition(ptr_ctx* ctx, uint32_t rank, uint32_t world);
  *      "extend.leaf_all"       1 (default): a leaf turn tests the lane's whole leaf; 0: one triangle per turn
  *      "extend.leaf_weight"    1, 2 (default), 4: how strongly lanes waiting at a leaf outvote lanes waiting at an
  *                              inner node when the wave picks the step kind of its next iteration
- *      "extend.blocks_per_cu"  persistent grid size of the traversal kernel, 1..64 blocks of 256 threads per CU (default 7)
+ *      "extend.blocks_per_cu"  persistent grid size of the traversal kernel, 1..64 blocks of 256 threads per CU (default 6: what stays resident at the kernel's register count)
  *      "frames.in_flight"      1..4 (default 2): "compute" dispatches of the wavefront pipeline run on that many internal
  *                              streams in turn, each with its own scratch, so that the tail of one frame overlaps the
  *                              start of the next.  The accumulate step (the only one that touches images) is ordered by

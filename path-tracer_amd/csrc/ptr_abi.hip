@@ -97,7 +97,7 @@ struct ptr_ctx {
     int opt_extend_leaf_all = 1;    // 1: a leaf turn tests every triangle of the leaf, 0: one triangle per turn
     int opt_extend_leaf_weight = 2; // leaf lanes count this many times when a traversal wave picks its next step kind
     int opt_extend_refill = 16;     // idle lanes that trigger a refill of the traversal wave (8, 16, 32, 48, 64)
-    int opt_extend_blocks_per_cu = 7;
+    int opt_extend_blocks_per_cu = 6;
     int opt_index_words = 3;        // layout of the index buffer: 3 = the reference's packed words, 4 = v0, v1, v2, material
     int opt_shade_pregather = 1;    // wavefront shade reads per-triangle records gathered once per scene
     // the records, and what they were built from: addresses + write generations of indices / positions / normals / uvs

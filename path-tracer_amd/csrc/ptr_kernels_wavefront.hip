@@ -110,6 +110,13 @@ PTR_DEV int32_t stack_pop(const int32_t* lds, const int32_t* spill, uint32_t sp)
     return v;
 }
 
+// wave-uniform copies of lane L's / the first lane's value: they live in scalar registers
+PTR_DEV float lane_value(float v, int lane_index) { return __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(v), lane_index)); }
+PTR_DEV int32_t lane_value(int32_t v, int lane_index) { return __builtin_amdgcn_readlane(v, lane_index); }
+PTR_DEV uint32_t lane_value(uint32_t v, int lane_index) { return (uint32_t)__builtin_amdgcn_readlane((int)v, lane_index); }
+PTR_DEV float uniform_value(float v) { return __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(v))); }
+PTR_DEV int32_t uniform_value(int32_t v) { return __builtin_amdgcn_readfirstlane(v); }
+
 constexpr int32_t kTraversalDone = INT32_MIN;  // never a leaf reference: triangle counts stay below 2^29
 
 // Persistent wave64 traversal.
@@ -131,7 +138,7 @@ constexpr int32_t kTraversalDone = INT32_MIN;  // never a leaf reference: triang
 //     reaches one takes its ray into the object's space, stacks a marker and goes on at the object's root; when the
 //     marker pops, the world-space ray is read back from the queue.  Both trees share the lane's one stack.
 template <bool STATS, int REFILL, int LEAF_WEIGHT, bool LEAF_ALL, int INNER_REPS, bool TWO_LEVEL>
-__global__ __launch_bounds__(kExtendThreads, 4) void ptr_wf_extend(FlatView fv, WavefrontScratch w, uint32_t gen, uint32_t slot_b,
+__global__ __launch_bounds__(kExtendThreads, TWO_LEVEL ? 6 : 4) void ptr_wf_extend(FlatView fv, WavefrontScratch w, uint32_t gen, uint32_t slot_b,
                                                                 unsigned long long* stats) {
     __shared__ int32_t lds_stack[(kExtendThreads / 64) * kStackLds * 64];
     const uint32_t lane = threadIdx.x & 63u;
@@ -189,7 +196,7 @@ __global__ __launch_bounds__(kExtendThreads, 4) void ptr_wf_extend(FlatView fv, 
             continue;  // re-evaluate: skipped entries leave lanes idle
         }
         if (idle == ~0ull) break;  // nothing in flight and my list is exhausted
-        if (!STATS && !TWO_LEVEL && next_k >= my_rays && __popcll(~idle) == 1) {
+        if (!STATS && next_k >= my_rays && __popcll(~idle) == 1) {
             // one ray left in the wave and nothing to fetch: after a while the whole wave finishes it together (below)
             if (++alone_turns > w.alone_turns) { lone_lane = (int)__ffsll((long long)~idle) - 1; break; }
         }
@@ -336,38 +343,60 @@ __global__ __launch_bounds__(kExtendThreads, 4) void ptr_wf_extend(FlatView fv, 
     // LDS; every turn up to 64 of them are popped, one per lane: a node lane tests its four children and appends the
     // ones the ray enters, a leaf lane tests its triangles.  Candidates are reduced with the rule of the sequential
     // walk (smaller t, on equal t the later rank), which does not depend on the visiting order, so the hit is the same.
-    if (!STATS && !TWO_LEVEL && lone_lane >= 0) {
-        int32_t* list = lds_stack + wave_in_block * kStackLds * 64;   // kStackLds * 64 entries, linear
-        constexpr uint32_t kListMax = kStackLds * 64;
+    // With placed copies every list entry carries the copy it belongs to (-1: top level) in a second array, the lane
+    // takes the world-space ray into that copy's space itself, and an instance leaf appends the object's root under
+    // the copy's number; the marker the single-lane walk keeps on its stack is not needed.
+    if (!STATS && lone_lane >= 0) {
+        int32_t* list = lds_stack + wave_in_block * kStackLds * 64;   // references, linear
+        constexpr uint32_t kListMax = TWO_LEVEL ? kStackLds * 32 : kStackLds * 64;
+        int32_t* list_copy = list + kListMax;                         // TWO_LEVEL: the copy of each entry
         constexpr uint32_t kWideLimit = kListMax - kStackMax - 8u;    // above this only the top entry is popped (depth-first: bounded growth)
-        const int L = lone_lane;
-        const f3 ro = mk3(__shfl(o.x, L), __shfl(o.y, L), __shfl(o.z, L));
-        const f3 rd = mk3(__shfl(d.x, L), __shfl(d.y, L), __shfl(d.z, L));
-        const f3 rinv = mk3(rcp(rd.x), rcp(rd.y), rcp(rd.z));
-        const bool ngx = (as_u32(rinv.x) >> 31) != 0u, ngy = (as_u32(rinv.y) >> 31) != 0u, ngz = (as_u32(rinv.z) >> 31) != 0u;
-        float bt = __shfl(best_t, L), bu = __shfl(best_u, L), bv = __shfl(best_v, L);
-        int32_t brank = __shfl(best_rank, L), bprim = __shfl(best_prim, L);
-        const uint32_t the_slot = __shfl(slot, L);
-        const uint32_t depth = __shfl(sp, L);
-        const int32_t top = __shfl(cur, L);
+        // everything about the ray is the same in all lanes from here on: kept in scalar registers
+        const int L = __builtin_amdgcn_readfirstlane(lone_lane);
+        const uint32_t the_slot = lane_value(slot, L);
+        f3 wo = mk3(lane_value(o.x, L), lane_value(o.y, L), lane_value(o.z, L));
+        f3 wd = mk3(lane_value(d.x, L), lane_value(d.y, L), lane_value(d.z, L));
+        if (TWO_LEVEL) {  // lane L may be inside a copy: the world-space ray is in the queue
+            const float4 qo = w.ray_o[gen][the_slot], qd = w.ray_d[gen][the_slot];
+            wo = mk3(uniform_value(qo.x), uniform_value(qo.y), uniform_value(qo.z));
+            wd = mk3(uniform_value(qd.x), uniform_value(qd.y), uniform_value(qd.z));
+        }
+        float bt = lane_value(best_t, L), bu = lane_value(best_u, L), bv = lane_value(best_v, L);
+        int32_t brank = lane_value(best_rank, L), bprim = lane_value(best_prim, L), bcopy = lane_value(best_inst, L);
+        const int32_t copy_of_l = lane_value(cur_inst, L);
+        const uint32_t depth = lane_value(sp, L);
+        int32_t top = lane_value(cur, L);
+        constexpr int32_t kMarker = ~(int32_t)(kInstanceTag | kLeaveInstance);
         // gather the lane-interleaved stack of lane L, then lay it out linearly (at most kStackMax + 3 entries: four per lane)
         const int32_t* spill_of_l = my_spill - lane + L;
         int32_t held[4];
+        uint32_t marker_at = 0xffffffffu;
         #pragma unroll
         for (uint32_t j = 0; j < 4u; j++) {
             const uint32_t e = lane + 64u * j;
-            held[j] = 0;
+            held[j] = kEmptyChild;
             if (e < depth) held[j] = e < kStackLds ? list[e * 64u + (uint32_t)L] : spill_of_l[(e - kStackLds) * 64u];
+            if (TWO_LEVEL) {
+                const unsigned long long found = __ballot(e < depth && held[j] == kMarker);
+                if (found != 0ull) marker_at = (uint32_t)__ffsll((long long)found) - 1u + 64u * j;
+            }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         #pragma unroll
         for (uint32_t j = 0; j < 4u; j++) {
             const uint32_t e = lane + 64u * j;
-            if (e < depth && e < kListMax) list[e] = held[j];
+            if (e < depth && e < kListMax) {
+                list[e] = (TWO_LEVEL && e == marker_at) ? kEmptyChild : held[j];
+                if (TWO_LEVEL) list_copy[e] = (marker_at != 0xffffffffu && e > marker_at) ? copy_of_l : -1;
+            }
         }
         uint32_t size = depth < kListMax ? depth : kListMax;
-        if (lane == 0u && top != kTraversalDone && size < kListMax) list[size] = top;
+        if (TWO_LEVEL && top == kMarker) top = kTraversalDone;   // the copy was finished: nothing of it is pending
+        if (lane == 0u && top != kTraversalDone && size < kListMax) {
+            list[size] = top;
+            if (TWO_LEVEL) list_copy[size] = copy_of_l;
+        }
         if (top != kTraversalDone) size++;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -378,19 +407,33 @@ __global__ __launch_bounds__(kExtendThreads, 4) void ptr_wf_extend(FlatView fv, 
             if (pops == 0u) pops = 1u;
             const bool mine = lane < pops;
             const int32_t ref = mine ? list[size - 1u - lane] : kEmptyChild;
+            int32_t copy = -1;
+            if (TWO_LEVEL && mine) copy = list_copy[size - 1u - lane];
             size -= pops;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
 
+            // this entry's ray: the world-space one, or that ray inside the entry's copy
+            f3 ro = wo, rd = wd;
+            if (TWO_LEVEL && copy >= 0) {
+                const float4* rec = fv.top.records + 4 * (size_t)copy;
+                const float4 m0 = rec[0], m1 = rec[1], m2 = rec[2];
+                ro = xform_point(m0, m1, m2, wo);
+                rd = xform_dir(m0, m1, m2, wd);
+            }
             int32_t r0 = kEmptyChild, r1 = kEmptyChild, r2 = kEmptyChild, r3 = kEmptyChild;
+            int32_t push_copy = copy;
             uint32_t n_push = 0u;
             float ct = __builtin_inff(), cu = 0.0f, cv = 0.0f;   // this lane's candidate hit
-            int32_t crank = -1, cprim = -1;
+            int32_t crank = -1, cprim = -1, ccopy = -1;
             if (mine && ref >= 0) {
-                const float4 q0 = fv.nodes[4 * ref];
-                const int4 refs = ((const int4*)fv.nodes)[4 * ref + 1];
-                const uint4 qa = ((const uint4*)fv.nodes)[4 * ref + 2];
-                const uint4 qb = ((const uint4*)fv.nodes)[4 * ref + 3];
+                const float4* level_nodes = (TWO_LEVEL && copy < 0) ? fv.top.nodes : fv.nodes;
+                const f3 rinv = mk3(rcp(rd.x), rcp(rd.y), rcp(rd.z));
+                const bool ngx = (as_u32(rinv.x) >> 31) != 0u, ngy = (as_u32(rinv.y) >> 31) != 0u, ngz = (as_u32(rinv.z) >> 31) != 0u;
+                const float4 q0 = level_nodes[4 * ref];
+                const int4 refs = ((const int4*)level_nodes)[4 * ref + 1];
+                const uint4 qa = ((const uint4*)level_nodes)[4 * ref + 2];
+                const uint4 qb = ((const uint4*)level_nodes)[4 * ref + 3];
                 const f3 A = mk3(q0.w * rinv.x, __uint_as_float(qb.z) * rinv.y, __uint_as_float(qb.w) * rinv.z);
                 const f3 B = mk3((q0.x - ro.x) * rinv.x, (q0.y - ro.y) * rinv.y, (q0.z - ro.z) * rinv.z);
                 const uint32_t near_x = ngx ? qa.w : qa.x, far_x = ngx ? qa.x : qa.w;
@@ -408,6 +451,12 @@ __global__ __launch_bounds__(kExtendThreads, 4) void ptr_wf_extend(FlatView fv, 
                 sort_pair(k1, r1, k3, r3);
                 sort_pair(k1, r1, k2, r2);
                 n_push = (k0 < inf ? 1u : 0u) + (k1 < inf ? 1u : 0u) + (k2 < inf ? 1u : 0u) + (k3 < inf ? 1u : 0u);  // hits are sorted to the front
+            } else if (TWO_LEVEL && mine && ref != kEmptyChild && copy < 0) {
+                // a leaf of the top level: the object's root, under the copy's number
+                const uint32_t index = (uint32_t)~ref & ~kInstanceTag;
+                r0 = __float_as_int(fv.top.records[4 * (size_t)index + 3].x);
+                push_copy = (int32_t)index;
+                n_push = 1u;
             } else if (mine && ref != kEmptyChild) {
                 uint32_t lr = (uint32_t)~ref;
                 for (;;) {
@@ -423,21 +472,27 @@ __global__ __launch_bounds__(kExtendThreads, 4) void ptr_wf_extend(FlatView fv, 
                     const float t = dd * dot(-n, ov);
                     const bool reject = u < 0.0f || u > 1.0f || v < 0.0f || u + v > 1.0f || t < min_t || t > bt || t != t || u != u || v != v;
                     const int32_t rank = __float_as_int(a.w);
-                    if (!reject && (t < ct || (t == ct && rank > crank))) { ct = t; cu = u; cv = v; crank = rank; cprim = __float_as_int(b.w); }
+                    if (!reject && (t < ct || (t == ct && rank > crank))) { ct = t; cu = u; cv = v; crank = rank; cprim = __float_as_int(b.w); ccopy = copy; }
                     if (remaining == 0u) break;
                     lr = ((first + 1u) << 2) | (remaining - 1u);
                 }
             }
-            // the best candidate of the turn: smallest t, then the later rank
+            // the best candidate of the turn: smallest t, then the later (copy, rank) pair
             if (__ballot(cprim >= 0) != 0ull) {
                 #pragma unroll
                 for (int off = 32; off > 0; off >>= 1) {
                     const float ot = __shfl_xor(ct, off), ou = __shfl_xor(cu, off), ov2 = __shfl_xor(cv, off);
                     const int32_t orank = __shfl_xor(crank, off), oprim = __shfl_xor(cprim, off);
-                    const bool take = oprim >= 0 && (cprim < 0 || ot < ct || (ot == ct && orank > crank));
-                    if (take) { ct = ot; cu = ou; cv = ov2; crank = orank; cprim = oprim; }
+                    const int32_t ocopy = TWO_LEVEL ? __shfl_xor(ccopy, off) : -1;
+                    const bool later = TWO_LEVEL ? (ocopy > ccopy || (ocopy == ccopy && orank > crank)) : orank > crank;
+                    const bool take = oprim >= 0 && (cprim < 0 || ot < ct || (ot == ct && later));
+                    if (take) { ct = ot; cu = ou; cv = ov2; crank = orank; cprim = oprim; ccopy = ocopy; }
                 }
-                if (cprim >= 0 && !(bprim >= 0 && ct == bt && crank < brank)) { bt = ct; bu = cu; bv = cv; brank = crank; bprim = cprim; }
+                // after the butterfly every lane holds the same candidate
+                ct = uniform_value(ct); cu = uniform_value(cu); cv = uniform_value(cv);
+                crank = uniform_value(crank); cprim = uniform_value(cprim); ccopy = uniform_value(ccopy);
+                const bool earlier = TWO_LEVEL ? (ccopy < bcopy || (ccopy == bcopy && crank < brank)) : crank < brank;
+                if (cprim >= 0 && !(bprim >= 0 && ct == bt && earlier)) { bt = ct; bu = cu; bv = cv; brank = crank; bprim = cprim; bcopy = ccopy; }
             }
             // append the entered children: farthest first within a lane, so that a depth-first turn pops the nearest
             const unsigned long long b0 = __ballot((n_push & 1u) != 0u), b1 = __ballot((n_push & 2u) != 0u), b2 = __ballot((n_push & 4u) != 0u);
@@ -446,6 +501,7 @@ __global__ __launch_bounds__(kExtendThreads, 4) void ptr_wf_extend(FlatView fv, 
             const uint32_t total = (uint32_t)__popcll(b0) + 2u * (uint32_t)__popcll(b1) + 4u * (uint32_t)__popcll(b2);
             if (size + total > kListMax) break;   // cannot happen while the header's stack bound holds; never write past the list
             uint32_t at = size + offset;
+            if (TWO_LEVEL) for (uint32_t j = 0; j < n_push; j++) list_copy[at + j] = push_copy;
             if (n_push > 3u) list[at++] = r3;
             if (n_push > 2u) list[at++] = r2;
             if (n_push > 1u) list[at++] = r1;
@@ -454,7 +510,10 @@ __global__ __launch_bounds__(kExtendThreads, 4) void ptr_wf_extend(FlatView fv, 
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
         }
-        if (lane == 0u) w.hits[the_slot] = make_float4(bt, bu, bv, __int_as_float(bprim));
+        if (lane == 0u) {
+            w.hits[the_slot] = make_float4(bt, bu, bv, __int_as_float(bprim));
+            if (TWO_LEVEL) w.hit_instance[the_slot] = bcopy;
+        }
     }
     if (STATS && stats) {
         for (int off = 32; off > 0; off >>= 1) {

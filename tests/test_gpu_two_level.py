@@ -107,3 +107,23 @@ def test_copies_of_two_objects_are_bit_exact_vs_oracle(ctx):
     same(cap[1], aov[1], "hit distances of the first two hits")
     same(img, ref, "image")
     assert {k: st[k] for k in ("rays", "nodes", "triangles", "shaded")} == {k: counters[k] for k in ("rays", "nodes", "triangles", "shaded")}
+
+
+@pytest.mark.parametrize("turns", [0, 2, 1000000])
+def test_last_ray_of_a_wave_in_a_two_level_scene(ctx, turns):
+    """extend.alone_turns with placed copies: the wave takes over a ray that may be inside a copy (marker on its stack, ray in
+    object space); every pending entry is tagged with its copy and the hit, copy included, comes out the same."""
+    from test_two_level import two_object_bundle
+    b = two_object_bundle(128, 80, max_bounce=5)
+    ctx.set_option("extend.alone_turns", turns)
+    try:
+        img, gs, cap, _ = gpu_frames(ctx, b, 3, "compute.wavefront", capture=True)
+        img2, _, _, _ = gpu_frames(ctx, b, 4, "compute.wavefront", gpu_scene=gs)
+    finally:
+        ctx.set_option("extend.alone_turns", 0)
+    ref, _, aov = oracle_for(b, gs, 3, use_flat=True, aov=True)
+    same(cap[0], aov[0], "copy * triangles + primitive of the first two hits")
+    same(cap[1], aov[1], "hit distances")
+    same(img, ref, f"image, alone_turns {turns}")
+    ref2, _, _ = oracle_for(b, gs, 4, use_flat=True)
+    same(img2, ref2, f"image of the overlapped frames, alone_turns {turns}")
