@@ -4,7 +4,7 @@ sides implement the same fully specified fp32 arithmetic -- whole images are com
 import numpy as np
 import pytest
 
-from common import gpu_frames, make_bundle, oracle_frames
+from common import gpu_frames, make_bundle, oracle_frames, parse
 
 pytestmark = pytest.mark.gpu
 
@@ -373,6 +373,51 @@ def test_last_ray_of_a_wave_finished_by_all_lanes(ctx, turns, kind, target, w, h
     assert_same(img, ref, f"image, alone_turns {turns}")
     ref2, _, _ = oracle_for(b, gs, 4, use_flat=True)
     assert_same(img2, ref2, f"image of the overlapped frames, alone_turns {turns}")
+
+
+def chain_layout(bundle, levels, claimed_depth):
+    """A hand-made flattened layout: a chain of `levels` nodes, each with the next node as its first child and three leaves that
+    all hold the scene's largest triangle, every child box equal to the whole scene -- a ray that enters stacks three entries per level."""
+    from path_tracer_amd import host
+    h0, _, tris0 = parse(bundle["flat"])
+    ti = tris0.view(np.int32)
+    area = np.linalg.norm(tris0[:, 12:15], axis=1)               # |e1 x e2|
+    tri = tris0[int(np.argmax(area))].copy()                     # the record of the largest triangle
+    lo, hi = h0["scene_min"].astype(np.float32), h0["scene_max"].astype(np.float32)
+    origin = lo - np.float32(1.0)
+    step = np.float32(2.0) ** np.ceil(np.log2((hi - origin + 1.0) / 255.0)).astype(np.float32)
+    nodes = np.zeros((levels, 16), np.float32)
+    ni, nu = nodes.view(np.int32), nodes.view(np.uint32)
+    leaf = ~np.int32(0)                                           # record 0 of this layout, one triangle
+    for k in range(levels):
+        nodes[k, 0:3] = origin; nodes[k, 3] = step[0]; nodes[k, 14] = step[1]; nodes[k, 15] = step[2]
+        ni[k, 4:8] = [k + 1 if k + 1 < levels else leaf, leaf, leaf, leaf]
+        nu[k, 8:11] = 0                                            # lower planes at the origin
+        nu[k, 11:14] = 0xFFFFFFFF                                  # upper planes 255 steps away
+    header = np.zeros(64, np.uint8)
+    header.view(np.uint32)[0:4] = [0x46525450, 2, levels, 1]
+    header.view(np.uint64)[2:4] = [64, 64 + 64 * levels]
+    header.view(np.int32)[8] = 0
+    header.view(np.uint32)[9] = claimed_depth
+    header.view(np.float32)[10:13] = lo; header.view(np.float32)[13:16] = hi
+    return np.concatenate([header, nodes.view(np.uint8).reshape(-1), tri.view(np.uint8).reshape(-1)])
+
+
+@pytest.mark.parametrize("claimed_depth", [130, 4])
+def test_deep_traversal_stacks(ctx, claimed_depth):
+    """42 levels x 3 pending entries: far past the 16 entries a lane keeps in LDS, so the spill area, the pops from it and the
+    wave takeover's gather of a deep stack all run.  With a header that understates its tree (4) the entries beyond the spill
+    area are dropped instead of stored outside it; they are duplicates here, so even that picture equals the oracle's."""
+    b = make_bundle("tiny", 0, 48, 32, max_bounce=3)
+    b = dict(b, flat=chain_layout(b, 42, claimed_depth))
+    img, gs, cap, _ = gpu_frames(ctx, b, 2, "compute.wavefront", capture=True)
+    ref, _, aov = oracle_for(b, gs, 2, use_flat=True, aov=True)
+    assert (aov[0][..., 0] >= 0).mean() > 0.02, "the triangle is in view"
+    assert_same(cap[0], aov[0], "primitive ids")
+    assert_same(img, ref, "image")
+    ok = make_bundle("tiny", 0, 48, 32, max_bounce=3)             # the context goes on working
+    img2, gs2, _, _ = gpu_frames(ctx, ok, 2, "compute.wavefront")
+    assert_same(img2, oracle_for(ok, gs2, 2, use_flat=True)[0], "next scene")
 
 
 def test_debug_bvh_heatmap(ctx):
