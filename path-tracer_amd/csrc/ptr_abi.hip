@@ -405,6 +405,21 @@ int validate_scene(ptr_ctx* c, const uint64_t addr[7], const ptr_handle handles[
     if (triangles && out[1] >= materials) return fail(c, PTR_E_RANGE, "scene: the index buffer names material %u, the material buffer holds %llu", out[1], (unsigned long long)materials);
     if (out[2]) return fail(c, PTR_E_RANGE, "scene: %u links or primitive ids of the bvh nodes point outside the node / index buffers", out[2]);
     if (out[3]) return fail(c, PTR_E_RANGE, "scene: %u child references or primitive ids of the flattened layout%s point outside it", out[3], top_buf ? " or of its instances" : "");
+    if (fv) {
+        // the kernels size their traversal stacks from the header's bound: measure what the tree really needs
+        uint32_t need = 0, top_need = 0;
+        int status = 0;
+        PTR_HIP_CHECK(c, ptr::measure_stack_need(c->stream, fv->nodes, flat_buf->flat_nodes, fv->root, ptr::kStackMax, &need, &status));
+        if (status == -3) return fail(c, PTR_E_RANGE, "scene: the flattened layout is not a tree (a node is reached along several paths)");
+        if (status != 0 || need > flat_buf->flat_view.max_depth)
+            return fail(c, PTR_E_RANGE, "scene: the flattened layout needs a deeper traversal stack than its header states (%u)", flat_buf->flat_view.max_depth);
+        if (top_buf) {
+            PTR_HIP_CHECK(c, ptr::measure_stack_need(c->stream, fv->top.nodes, top_buf->top_nodes, fv->top.root, ptr::kStackMax, &top_need, &status));
+            if (status == -3) return fail(c, PTR_E_RANGE, "scene: the top level over the instances is not a tree");
+            if (status != 0 || top_need + 1u + flat_buf->flat_view.max_depth > top_buf->top_depth)
+                return fail(c, PTR_E_RANGE, "scene: the instances need a deeper traversal stack than their header states (%u)", top_buf->top_depth);
+        }
+    }
     ptr_ctx::Validated& slot = c->validated[c->validated_next];
     c->validated_next = (c->validated_next + 1) % 4;
     memcpy(slot.key, key, sizeof key);

@@ -87,6 +87,11 @@ hipError_t build_flat_bvh(hipStream_t s, const SceneView& sv, uint32_t triangle_
 hipError_t launch_validate_scene(hipStream_t s, const SceneView& sv, uint32_t triangle_count, uint32_t threaded_nodes, const FlatView* fv,
                                  uint32_t flat_nodes, uint32_t flat_triangles, uint32_t top_nodes, uint32_t* out4);
 
+// Stack entries a depth-first walk of the 4-wide tree at `nodes` can have pending at once (the figure a layout header
+// claims as max_depth), measured level by level.  Synchronous.  *status: 0 ok, -1 bad root, -2 more than `limit`
+// (or a cycle), -3 a node reached along several paths.  Child references must have been range-checked before.
+hipError_t measure_stack_need(hipStream_t s, const float4* nodes, uint32_t node_count, int32_t root, uint32_t limit, uint32_t* need, int* status);
+
 // Per-function test kernel (ptr_kernels_unit.hip): index of `name` (< 0 if unknown) with its record sizes in 32-bit words.
 int unit_function_lookup(const char* name, uint32_t* in_words, uint32_t* out_words);
 hipError_t launch_unit_function(hipStream_t s, int fn, const uint32_t* in, uint32_t in_words, uint32_t* out, uint32_t out_words, uint32_t count);

@@ -91,7 +91,83 @@ __global__ __launch_bounds__(256) void validate_top(InstanceView top, uint32_t t
     if (bad) atomicAdd(&out[3], bad);
 }
 
+// One level of the tree, breadth first: every frontier node hands its inner children on, each with the number of
+// references that can be pending on a depth-first walk's stack when it is entered (the parent's figure plus the parent's
+// other children).  counters: [0] next frontier length, [1] largest figure seen, [2] frontier overflow (a node reached
+// along more than one path: not a tree).  One atomic per wave.
+struct DepthItem { uint32_t node, pending; };
+__global__ __launch_bounds__(256) void depth_level(const float4* nodes, uint32_t node_count, const DepthItem* in, uint32_t count, DepthItem* out,
+                                                   uint32_t capacity, uint32_t* counters) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t lane = threadIdx.x & 63u;
+    int32_t r[4] = { INT32_MIN, INT32_MIN, INT32_MIN, INT32_MIN };
+    uint32_t pending = 0u, inner = 0u;
+    if (i < count) {
+        const DepthItem item = in[i];
+        const int4 refs = ((const int4*)nodes)[4 * (size_t)item.node + 1];
+        r[0] = refs.x; r[1] = refs.y; r[2] = refs.z; r[3] = refs.w;
+        uint32_t children = 0u;
+        for (int k = 0; k < 4; k++) {
+            if (r[k] == INT32_MIN) continue;
+            children++;
+            if (r[k] >= 0 && (uint32_t)r[k] < node_count) inner++; else if (r[k] >= 0) r[k] = INT32_MIN;
+        }
+        pending = item.pending + (children ? children - 1u : 0u);
+        atomicMax(&counters[1], pending);
+    }
+    // wave-wide exclusive prefix of `inner` (0..4): three ballots, one per bit
+    const unsigned long long b0 = __ballot((inner & 1u) != 0u), b1 = __ballot((inner & 2u) != 0u), b2 = __ballot((inner & 4u) != 0u);
+    const unsigned long long below = (1ull << lane) - 1ull;
+    const uint32_t offset = (uint32_t)__popcll(b0 & below) + 2u * (uint32_t)__popcll(b1 & below) + 4u * (uint32_t)__popcll(b2 & below);
+    const uint32_t total = (uint32_t)__popcll(b0) + 2u * (uint32_t)__popcll(b1) + 4u * (uint32_t)__popcll(b2);
+    uint32_t base = 0u;
+    if (lane == 0u && total) base = atomicAdd(&counters[0], total);
+    base = __shfl(base, 0);
+    uint32_t at = base + offset;
+    for (int k = 0; k < 4; k++) {
+        if (r[k] < 0) continue;
+        if (at < capacity) { DepthItem next; next.node = (uint32_t)r[k]; next.pending = pending; out[at] = next; }
+        else counters[2] = 1u;
+        at++;
+    }
+}
+
 }  // namespace
+
+hipError_t measure_stack_need(hipStream_t s, const float4* nodes, uint32_t node_count, int32_t root, uint32_t limit, uint32_t* need, int* status) {
+    *need = 0u; *status = 0;
+    if (root < 0 || node_count == 0u) return hipSuccess;     // the root is a leaf: nothing is ever pending
+    if ((uint32_t)root >= node_count) { *status = -1; return hipSuccess; }
+    DepthItem* frontier[2] = { nullptr, nullptr };
+    uint32_t* counters = nullptr;
+    auto cleanup = [&]() { (void)hipFree(frontier[0]); (void)hipFree(frontier[1]); (void)hipFree(counters); };
+    hipError_t e;
+    if ((e = hipMalloc((void**)&frontier[0], (size_t)node_count * sizeof(DepthItem))) != hipSuccess) { cleanup(); return e; }
+    if ((e = hipMalloc((void**)&frontier[1], (size_t)node_count * sizeof(DepthItem))) != hipSuccess) { cleanup(); return e; }
+    if ((e = hipMalloc((void**)&counters, 16)) != hipSuccess) { cleanup(); return e; }
+    const DepthItem first{ (uint32_t)root, 0u };
+    uint32_t host[4] = { 0u, 0u, 0u, 0u };
+    if ((e = hipMemcpyAsync(frontier[0], &first, sizeof first, hipMemcpyHostToDevice, s)) != hipSuccess) { cleanup(); return e; }
+    if ((e = hipMemcpyAsync(counters, host, sizeof host, hipMemcpyHostToDevice, s)) != hipSuccess) { cleanup(); return e; }
+    uint32_t count = 1u;
+    int cur = 0;
+    // every level adds at least one pending reference, so a tree within the limit has at most limit + 1 levels
+    for (uint32_t level = 0; count > 0u; level++) {
+        if (level > limit + 1u) { *status = -2; break; }
+        if ((e = hipMemsetAsync(counters, 0, 4, s)) != hipSuccess) { cleanup(); return e; }
+        hipLaunchKernelGGL(depth_level, dim3((count + 255u) / 256u), dim3(256), 0, s, nodes, node_count, frontier[cur], count, frontier[cur ^ 1], node_count, counters);
+        if ((e = hipGetLastError()) != hipSuccess) { cleanup(); return e; }
+        if ((e = hipMemcpyAsync(host, counters, sizeof host, hipMemcpyDeviceToHost, s)) != hipSuccess) { cleanup(); return e; }
+        if ((e = hipStreamSynchronize(s)) != hipSuccess) { cleanup(); return e; }
+        if (host[2] != 0u || host[0] > node_count) { *status = -3; break; }
+        if (host[1] > limit) { *status = -2; break; }
+        count = host[0];
+        cur ^= 1;
+    }
+    *need = host[1];
+    cleanup();
+    return hipSuccess;
+}
 
 hipError_t launch_validate_scene(hipStream_t s, const SceneView& sv, uint32_t triangle_count, uint32_t threaded_nodes, const FlatView* fv,
                                  uint32_t flat_nodes, uint32_t flat_triangles, uint32_t top_nodes, uint32_t* out4) {

@@ -117,13 +117,6 @@ PTR_DEV uint32_t lane_value(uint32_t v, int lane_index) { return (uint32_t)__bui
 PTR_DEV float uniform_value(float v) { return __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(v))); }
 PTR_DEV int32_t uniform_value(int32_t v) { return __builtin_amdgcn_readfirstlane(v); }
 
-// Push past the LDS part of the stack.  The spill area is sized from the layout header's stack bound; an entry beyond it
-// (a header that understates its tree) is dropped rather than written outside the lane's area: a wrong picture, no wild store.
-PTR_DEV void stack_push_deep(int32_t* lds, int32_t* spill, uint32_t spill_entries, uint32_t& sp, int32_t ref) {
-    if (sp < kStackLds) { lds[sp * 64u] = ref; sp++; }
-    else if (sp - kStackLds < spill_entries) { spill[(sp - kStackLds) * 64u] = ref; sp++; }
-}
-
 constexpr int32_t kTraversalDone = INT32_MIN;  // never a leaf reference: triangle counts stay below 2^29
 
 // Persistent wave64 traversal.
@@ -254,9 +247,9 @@ __global__ __launch_bounds__(kExtendThreads, TWO_LEVEL ? 6 : 4) void ptr_wf_exte
                     my_lds[sp * 64u] = r2; sp += (k2 < inf) ? 1u : 0u;
                     my_lds[sp * 64u] = r1; sp += (k1 < inf) ? 1u : 0u;
                 } else {
-                    if (k3 < inf) stack_push_deep(my_lds, my_spill, w.spill_entries, sp, r3);
-                    if (k2 < inf) stack_push_deep(my_lds, my_spill, w.spill_entries, sp, r2);
-                    if (k1 < inf) stack_push_deep(my_lds, my_spill, w.spill_entries, sp, r1);
+                    if (k3 < inf) { if (sp < kStackLds) my_lds[sp * 64u] = r3; else my_spill[(sp - kStackLds) * 64u] = r3; sp++; }
+                    if (k2 < inf) { if (sp < kStackLds) my_lds[sp * 64u] = r2; else my_spill[(sp - kStackLds) * 64u] = r2; sp++; }
+                    if (k1 < inf) { if (sp < kStackLds) my_lds[sp * 64u] = r1; else my_spill[(sp - kStackLds) * 64u] = r1; sp++; }
                 }
                 cur = r0;
             } else if (sp == 0u) {
@@ -292,7 +285,8 @@ __global__ __launch_bounds__(kExtendThreads, TWO_LEVEL ? 6 : 4) void ptr_wf_exte
                     d = xform_dir(r0, r1, r2, wd);
                     cur_inst = (int32_t)index;
                     const int32_t marker = ~(int32_t)(kInstanceTag | kLeaveInstance);
-                    stack_push_deep(my_lds, my_spill, w.spill_entries, sp, marker);
+                    if (sp < kStackLds) my_lds[sp * 64u] = marker; else my_spill[(sp - kStackLds) * 64u] = marker;
+                    sp++;
                     cur = object_root;
                 }
                 inv = mk3(rcp(d.x), rcp(d.y), rcp(d.z));

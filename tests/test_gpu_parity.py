@@ -403,18 +403,40 @@ def chain_layout(bundle, levels, claimed_depth):
     return np.concatenate([header, nodes.view(np.uint8).reshape(-1), tri.view(np.uint8).reshape(-1)])
 
 
-@pytest.mark.parametrize("claimed_depth", [130, 4])
-def test_deep_traversal_stacks(ctx, claimed_depth):
+def test_deep_traversal_stacks(ctx):
     """42 levels x 3 pending entries: far past the 16 entries a lane keeps in LDS, so the spill area, the pops from it and the
-    wave takeover's gather of a deep stack all run.  With a header that understates its tree (4) the entries beyond the spill
-    area are dropped instead of stored outside it; they are duplicates here, so even that picture equals the oracle's."""
+    wave takeover's gather of a deep stack all run."""
     b = make_bundle("tiny", 0, 48, 32, max_bounce=3)
-    b = dict(b, flat=chain_layout(b, 42, claimed_depth))
+    b = dict(b, flat=chain_layout(b, 42, 130))
     img, gs, cap, _ = gpu_frames(ctx, b, 2, "compute.wavefront", capture=True)
     ref, _, aov = oracle_for(b, gs, 2, use_flat=True, aov=True)
     assert (aov[0][..., 0] >= 0).mean() > 0.02, "the triangle is in view"
     assert_same(cap[0], aov[0], "primitive ids")
     assert_same(img, ref, "image")
+
+
+def test_layout_header_that_understates_its_stack_is_refused(ctx):
+    """The kernels size their stacks from the header's bound, so the library measures the tree before the first dispatch:
+    42 levels x 3 pending entries under a header that says 4 fail the dispatch; so does a node reached along two paths."""
+    from path_tracer_amd import hip
+    b = make_bundle("tiny", 0, 48, 32, max_bounce=3)
+
+    def attempt(flat):
+        scene = dict(b, flat=flat)
+        gs = hip.GpuScene(ctx, scene, scene["nodes"], scene["flat"], scene["meta"])
+        hip.FrameLoop(ctx, gs, 48, 32, "compute.wavefront").frame()
+
+    with pytest.raises(hip.HipError, match="deeper traversal stack"):
+        attempt(chain_layout(b, 42, 4))
+    with pytest.raises(hip.HipError, match="deeper traversal stack"):
+        attempt(chain_layout(b, 42, 125))                         # one short of the 126 it needs
+    attempt(chain_layout(b, 42, 126))
+    shared = chain_layout(b, 6, 130)
+    shared[64 + 16:64 + 32].view(np.int32)[1:4] = 1               # node 0 names node 1 four times over
+    shared[64 + 64 + 16:64 + 64 + 32].view(np.int32)[1:4] = 2     # ... and so on: the frontier outgrows the node array
+    shared[64 + 128 + 16:64 + 128 + 32].view(np.int32)[1:4] = 3
+    with pytest.raises(hip.HipError, match="not a tree"):
+        attempt(shared)
     ok = make_bundle("tiny", 0, 48, 32, max_bounce=3)             # the context goes on working
     img2, gs2, _, _ = gpu_frames(ctx, ok, 2, "compute.wavefront")
     assert_same(img2, oracle_for(ok, gs2, 2, use_flat=True)[0], "next scene")
