@@ -220,7 +220,13 @@ def main():
         ctx = hip.Context(local_rank, stream=stream.cuda_stream if args.stream == "torch" else None)
         for kv in filter(None, os.environ.get("PTR_BENCH_OPTIONS", "").split(",")):   # tuning experiments: "key=value,key=value"
             ctx.set_option(kv.split("=")[0], int(kv.split("=")[1]))
+        t_up = time.perf_counter()
         gpu = hip.GpuScene(ctx, sc, nodes, flat, meta)
+        ctx.sync()
+        # the one-time host -> device copy of the scene (pageable host memory): never part of the timed region
+        build_times["upload_s"] = time.perf_counter() - t_up
+        build_times["upload_mb"] = sum(int(np.asarray(sc[k]).nbytes) for k in ("indices", "positions", "normals", "uvs")) / 1e6 \
+            + (0 if flat is None else flat.nbytes / 1e6) + nodes.nbytes / 1e6 + sum(t.nbytes for t in sc["textures"] if t is not None) / 1e6
         if args.bvh == "gpu":
             gpu.wire(ctx.create_compute_renderpass())          # the context's index layout for this scene
             ctx.profile_enable(True)
@@ -294,6 +300,12 @@ def main():
         ctx.profile_enable(False)
         prof = ctx.profile_read(reset=True)
         ctx.set_option("profile.extend_only", 0)
+
+        # what a caller pays on top when it reads every finished frame back over PCIe (33 MB at 1080p)
+        t_rb = time.perf_counter()
+        for _ in range(3):
+            loop.latest().read()
+        build_times["frame_readback_ms"] = (time.perf_counter() - t_rb) / 3 * 1e3
 
         # per-kernel split of a frame that has the GPU to itself (one frame in flight), outside the timed region
         loop.reset()
