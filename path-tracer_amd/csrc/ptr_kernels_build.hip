@@ -11,6 +11,7 @@
 //      than entering its two children (evaluated bottom-up together with the boxes; the triangles of a subtree are
 //      contiguous in sorted order, so triangle records are simply written in sorted order); wide nodes level by level from the root: a node adopts its two children and keeps replacing
 //      the inner child of largest surface area by that child's children until it has four
+//   6. the wide nodes are put in the order of the radix-tree nodes they grew from (Morton order, deterministic)
 #pragma clang fp contract(off)
 
 #include <hipcub/hipcub.hpp>
@@ -247,7 +248,7 @@ PTR_DEV bool quantise_axis(float node_lo, float node_hi, const float* lo, const 
 // One wide node per frontier entry.  counters: [0] wide nodes allocated, [1] next frontier length, [2] stack need, [3] failure flag.
 __global__ __launch_bounds__(128) void build_collapse(uint32_t count, const Frontier* in, Frontier* out, const BuildNode* nodes, const uint32_t* vals,
                                                       const float4* box_lo, const float4* box_hi, float4* out_nodes, uint32_t* counters,
-                                                      uint32_t node_capacity) {
+                                                      uint32_t node_capacity, uint32_t* wide_of) {
     const uint32_t f = blockIdx.x * 128u + threadIdx.x;
     if (f >= count) return;
     const Frontier item = in[f];
@@ -307,11 +308,34 @@ __global__ __launch_bounds__(128) void build_collapse(uint32_t count, const Fron
         for (uint32_t k = 0; k < n_children; k++) { lo[k] = boxes[k].lo[a]; hi[k] = boxes[k].hi[a]; }
         if (!quantise_axis(self.lo[a], self.hi[a], lo, hi, n_children, origin[a], step[a], qlo[a], qhi[a])) { counters[3] = 2u; return; }
     }
+    wide_of[item.wide] = item.node;
     float4* nd = out_nodes + 4 * (size_t)item.wide;
     nd[0] = make_float4(origin[0], origin[1], origin[2], step[0]);
     nd[1] = make_float4(__int_as_float(refs[0]), __int_as_float(refs[1]), __int_as_float(refs[2]), __int_as_float(refs[3]));
     nd[2] = make_float4(__uint_as_float(qlo[0]), __uint_as_float(qlo[1]), __uint_as_float(qlo[2]), __uint_as_float(qhi[0]));
     nd[3] = make_float4(__uint_as_float(qhi[1]), __uint_as_float(qhi[2]), step[1], step[2]);
+}
+
+// ---- 6. memory order of the wide nodes ---------------------------------------------------------------------
+// The level loop numbers nodes through an atomic counter: breadth first, in no particular order within a level, and
+// differently from run to run.  The final order is that of the radix-tree nodes they grew from, which follows the
+// Morton curve: neighbours in space are neighbours in memory, and the same scene always gives the same blob.
+__global__ __launch_bounds__(256) void build_rank(uint32_t count, const uint32_t* old_of_new, uint32_t* new_of_old) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i < count) new_of_old[old_of_new[i]] = i;
+}
+__global__ __launch_bounds__(256) void build_relayout(uint32_t count, const uint32_t* old_of_new, const uint32_t* new_of_old, const float4* in, float4* out) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= count) return;
+    const float4* src = in + 4 * (size_t)old_of_new[i];
+    float4* dst = out + 4 * (size_t)i;
+    const float4 refs = src[1];
+    int32_t r[4] = { __float_as_int(refs.x), __float_as_int(refs.y), __float_as_int(refs.z), __float_as_int(refs.w) };
+    for (int k = 0; k < 4; k++) if (r[k] >= 0) r[k] = (int32_t)new_of_old[r[k]];
+    dst[0] = src[0];
+    dst[1] = make_float4(__int_as_float(r[0]), __int_as_float(r[1]), __int_as_float(r[2]), __int_as_float(r[3]));
+    dst[2] = src[2];
+    dst[3] = src[3];
 }
 
 struct FlatHeader {
@@ -336,7 +360,7 @@ hipError_t build_flat_bvh(hipStream_t s, const SceneView& sv, uint32_t n, uint32
     *status = 0;
     if (n == 0 || vertex_count == 0 || blob_bytes < flat_build_blob_bytes(n)) { *status = -1; return hipSuccess; }
     const uint32_t node_capacity = n;
-    void* pool[12] = {};
+    void* pool[16] = {};
     int pooled = 0;
     auto cleanup = [&]() { for (int i = 0; i < pooled; i++) (void)hipFree(pool[i]); };
     auto take = [&](size_t bytes, void** out) -> hipError_t {
@@ -404,7 +428,7 @@ hipError_t build_flat_bvh(hipStream_t s, const SceneView& sv, uint32_t n, uint32
             if (level > 4096) { *status = -2; cleanup(); return hipSuccess; }
             BUILD_CHECK(hipMemsetAsync(counters + 1, 0, 4, s));
             hipLaunchKernelGGL(build_collapse, dim3((level_count + 127u) / 128u), dim3(128), 0, s, level_count, frontier[cur], frontier[cur ^ 1], nodes,
-                               vals_sorted, box_lo, box_hi, out_nodes, counters, node_capacity);
+                               vals_sorted, box_lo, box_hi, out_nodes, counters, node_capacity, visits);
             BUILD_CHECK(hipGetLastError());
             BUILD_CHECK(hipMemcpyAsync(host_scene, scene, sizeof host_scene, hipMemcpyDeviceToHost, s));
             BUILD_CHECK(hipStreamSynchronize(s));
@@ -417,6 +441,27 @@ hipError_t build_flat_bvh(hipStream_t s, const SceneView& sv, uint32_t n, uint32
         hd.node_count = host_scene[8 + 0];
         hd.max_depth = host_scene[8 + 2];
         if (hd.max_depth > kStackMax) { *status = -5; cleanup(); return hipSuccess; }
+        {
+            // order the wide nodes by the radix-tree node each grew from (visits[] holds that id since the level loop;
+            // the arrays of the earlier stages are free again and serve as sort buffers).  The root grew from node 0 and stays first.
+            const uint32_t wide = hd.node_count;
+            uint32_t* wide_of = visits;
+            uint32_t* sorted_of = (uint32_t*)node_parent;     // keys out
+            uint32_t* old_of_new = (uint32_t*)leaf_parent;    // values out: the old index of every new position
+            uint32_t* new_of_old = (uint32_t*)keys;
+            size_t bytes = 0;
+            BUILD_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, wide_of, sorted_of, vals, old_of_new, (int)wide, 0, 32, s));
+            void* temp = nullptr;
+            BUILD_CHECK(take(bytes, &temp));
+            BUILD_CHECK(hipcub::DeviceRadixSort::SortPairs(temp, bytes, wide_of, sorted_of, vals, old_of_new, (int)wide, 0, 32, s));
+            float4* moved = nullptr;
+            BUILD_CHECK(take((size_t)wide * 64, (void**)&moved));
+            const uint32_t wb = (wide + 255u) / 256u;
+            hipLaunchKernelGGL(build_rank, dim3(wb), dim3(256), 0, s, wide, old_of_new, new_of_old);
+            hipLaunchKernelGGL(build_relayout, dim3(wb), dim3(256), 0, s, wide, old_of_new, new_of_old, out_nodes, moved);
+            BUILD_CHECK(hipGetLastError());
+            BUILD_CHECK(hipMemcpyAsync(out_nodes, moved, (size_t)wide * 64, hipMemcpyDeviceToDevice, s));
+        }
     }
     // scene box: decode the ordered integers on the host
     for (int a = 0; a < 6; a++) {

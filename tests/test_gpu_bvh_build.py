@@ -87,3 +87,17 @@ def test_build_errors(ctx):
     with pytest.raises(hip.HipError):
         ctx.build_flat(idx, pos, 4)          # the index buffer holds 3 triangles
     idx.destroy(); pos.destroy()
+
+
+def test_the_same_scene_gives_the_same_blob(ctx):
+    """The level loop numbers nodes through an atomic counter; the final pass orders them by the radix-tree node each grew
+    from, so two builds agree byte for byte (header, nodes and triangle records)."""
+    sc = scenes.generate("atrium", 60000, seed=3, texture_size=16)
+    a = build_from_triangles(ctx, sc["triangles"])
+    b = build_from_triangles(ctx, sc["triangles"])
+    assert a.nbytes == b.nbytes
+    h = check_flat_layout(a, sc["triangles"], np.arange(sc["triangles"].shape[0]), tight=False)
+    used = 64 + 64 * h["node_count"]
+    assert np.array_equal(a[:used], b[:used]), "header and nodes"
+    t0 = h["triangles_offset"]
+    assert np.array_equal(a[t0:t0 + 64 * h["triangle_count"]], b[t0:t0 + 64 * h["triangle_count"]]), "triangle records"
