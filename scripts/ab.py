@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """A/B timing of tuning knobs in ONE process (interleaved rounds, same scene, same GPU):
-   python scripts/ab.py --configs "extend.fetch=0" "extend.fetch=1" "extend.fetch=0,extend.blocks_per_cu=6"
+   python scripts/ab.py --configs "extend.refill=16" "extend.refill=32" "extend.refill=16,extend.blocks_per_cu=7"
+(options persist from one configuration to the next: name every key in every configuration)
 Prints per-config median / min ms per frame and the per-kernel split from the library's HIP-event profiler."""
 import argparse
 import json
@@ -16,7 +17,7 @@ sys.path.insert(0, ROOT)
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--configs", nargs="+", default=["extend.fetch=0", "extend.fetch=1"])
+    ap.add_argument("--configs", nargs="+", default=["extend.refill=16", "extend.refill=32"])
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--frames", type=int, default=20)
     ap.add_argument("--triangles", type=int, default=2_800_000)
