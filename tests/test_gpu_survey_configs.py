@@ -76,3 +76,62 @@ def test_c4_street_exterior_4k_tile_mode(ctx):
     finally:
         ctx.set_partition(0, 1, 8)
     assert np.array_equal(merged, whole)
+
+
+def test_c5_placed_copies_sample_partition_vs_sequential(ctx):
+    """C5's shape at a size the CPU can follow: a scene of placed copies, the samples dealt out to 4 ranks (four partitions of
+    one context here), every rank's running mean linearised, summed (what the all-reduce does) and resolved.  The result is
+    not bit-equal to 16 sequential samples on one GPU -- each frame's clamp + sRGB round trip is nonlinear -- so it is held to
+    an RMSE bound on linear luminance, and the ranks' partial images are checked to be different samples of the same picture."""
+    from path_tracer_amd import hip, host, scenes
+    world, per_rank = 4, 4
+    W, H = 320, 180
+    base = make_bundle("street_exterior", 60000, W, H, max_bounce=4)
+    m = scenes.grid_transforms(base, 3, 3)
+    two = dict(base, flat_instances=host.bvh_flatten_instances(base["flat"], m))
+    gs = hip.GpuScene(ctx, two, two["nodes"], two["flat"], two["meta"])
+
+    def srgb_to_linear(c):
+        c = np.clip(c.astype(np.float64), 0, 1)
+        return np.where(c < 0.04045, c / 12.92, ((c + 0.055) / 1.055) ** 2.4)
+
+    def luminance(rgb):
+        return rgb @ np.array([0.2126, 0.7152, 0.0722])
+
+    linear = []
+    try:
+        for rank in range(world):
+            ctx.set_sample_partition(rank, world)
+            gs.set_meta(two["meta"])
+            loop = hip.FrameLoop(ctx, gs, W, H, "compute.wavefront")
+            for _ in range(per_rank):
+                loop.frame()
+            rp = ctx.create_compute_renderpass()
+            rp.set_pipeline("linearize")
+            rp.set_ouput_texture(loop.output)
+            rp.set_constant(60, loop.latest())
+            rp.set_dispatch_size(1, 1, 1)
+            rp.execute()
+            linear.append(loop.output.read())
+        total = np.sum(linear, axis=0).astype(np.float32)
+        assert (total[..., 3] == world).all()
+        loop.output.update(total)
+        rp.set_pipeline("resolve")
+        rp.set_ouput_texture(loop.latest())
+        rp.set_constant(60, loop.output)
+        rp.execute()
+        combined = loop.latest().read()
+    finally:
+        ctx.set_sample_partition(0, 1)
+    gs.set_meta(two["meta"])
+    seq_loop = hip.FrameLoop(ctx, gs, W, H, "compute.wavefront")
+    for _ in range(world * per_rank):
+        seq_loop.frame()
+    sequential = seq_loop.latest().read()
+    la, lb = luminance(srgb_to_linear(combined[..., :3])), luminance(srgb_to_linear(sequential[..., :3]))
+    rmse = float(np.sqrt(np.mean((la - lb) ** 2)))
+    assert rmse < 0.02, rmse
+    assert abs(la.mean() - lb.mean()) < 0.004, (la.mean(), lb.mean())
+    # the partial images are different samples (not four copies of one), each noisier than the combination
+    l0, l1 = luminance(linear[0][..., :3].astype(np.float64)), luminance(linear[1][..., :3].astype(np.float64))
+    assert float(np.sqrt(np.mean((l0 - l1) ** 2))) > 2 * rmse
