@@ -8,6 +8,7 @@ ap.add_argument("--triangles", type=int, default=2_800_000); ap.add_argument("--
 ap.add_argument("--width", type=int, default=1920); ap.add_argument("--height", type=int, default=1080)
 ap.add_argument("--texture-size", type=int, default=512); ap.add_argument("--bounces", type=int, default=4)
 ap.add_argument("--set", nargs="*", default=[], help="library options, key=value")
+ap.add_argument("--instances", default="1x1"); ap.add_argument("--two-level", action="store_true")
 args = ap.parse_args()
 import bench
 from path_tracer_amd import hip
