@@ -134,12 +134,12 @@ constexpr int32_t kTraversalDone = INT32_MIN;  // never a leaf reference: triang
 //   * The grid is the same for every launch of a frame.  Sharing a short queue among fewer waves (so that each keeps
 //     ~300 rays and drains less) was measured: slower at every setting -- parallelism beats lane utilisation here.
 //   * Per-lane stack: kStackLds entries in LDS (lane-interleaved, conflict-free), deeper entries in global memory.
-//     (Entering and leaving a copy each cost the lane a leaf turn.  Doing both where the reference becomes current, or as
-//     one repetition of an inner turn, was measured: 10 % slower -- the record and queue loads stall the whole wave
-//     inside its inner turn, and the extra live registers cost a resident wave.)
 //   * TWO_LEVEL: the tree in fv.top is walked first; its leaves name placed copies of the tree in fv.  A lane that
 //     reaches one takes its ray into the object's space, stacks a marker and goes on at the object's root; when the
 //     marker pops, the world-space ray is read back from the queue.  Both trees share the lane's one stack.
+//     (Entering and leaving a copy each cost the lane a leaf turn.  Doing both where the reference becomes current, or as
+//     one repetition of an inner turn, was measured: 10 % slower -- the record and queue loads stall the whole wave
+//     inside its inner turn, and the extra live registers cost a resident wave.)
 template <bool STATS, int REFILL, int LEAF_WEIGHT, bool LEAF_ALL, int INNER_REPS, bool TWO_LEVEL>
 __global__ __launch_bounds__(kExtendThreads, TWO_LEVEL ? 6 : 4) void ptr_wf_extend(FlatView fv, WavefrontScratch w, uint32_t gen, uint32_t slot_b,
                                                                 unsigned long long* stats) {
