@@ -353,7 +353,6 @@ __global__ __launch_bounds__(kExtendThreads, TWO_LEVEL ? 6 : 4) void ptr_wf_exte
         int32_t* list = lds_stack + wave_in_block * kStackLds * 64;   // references, linear
         constexpr uint32_t kListMax = TWO_LEVEL ? kStackLds * 32 : kStackLds * 64;
         int32_t* list_copy = list + kListMax;                         // TWO_LEVEL: the copy of each entry
-        constexpr uint32_t kWideLimit = kListMax - kStackMax - 8u;    // above this only the top entry is popped (depth-first: bounded growth)
         // everything about the ray is the same in all lanes from here on: kept in scalar registers
         const int L = __builtin_amdgcn_readfirstlane(lone_lane);
         const uint32_t the_slot = lane_value(slot, L);
@@ -404,15 +403,45 @@ __global__ __launch_bounds__(kExtendThreads, TWO_LEVEL ? 6 : 4) void ptr_wf_exte
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
 
-        while (size > 0u) {
-            uint32_t pops = size < 64u ? size : 64u;
-            if (size + 3u * pops > kWideLimit) pops = size >= kWideLimit ? 1u : (kWideLimit - size) / 3u;
-            if (pops == 0u) pops = 1u;
+        // The list is a ring in LDS, [tail, head); when a turn's appends might not fit, its oldest block moves out to the
+        // wave's spill area in global memory (free: lane L's deep entries were copied out above), and comes back when the
+        // ring runs low -- so a ray whose frontier is thousands of references wide still gets 64 lanes per turn.
+        constexpr uint32_t kMask = kListMax - 1u;
+        constexpr uint32_t kBlock = kListMax / 4u;
+        int32_t* overflow = w.stack_spill + (size_t)global_wave * w.spill_entries * 64u;
+        const uint32_t overflow_cap = ((w.spill_entries * 64u) / (TWO_LEVEL ? 2u : 1u)) / kBlock * kBlock;
+        int32_t* overflow_copy = overflow + overflow_cap;              // TWO_LEVEL: the copies of the entries moved out
+        uint32_t tail = 0u, head = size, moved_out = 0u;
+        while (head != tail || moved_out != 0u) {
+            if (head - tail < 64u && moved_out != 0u) {                // bring the newest block back below the ring
+                tail -= kBlock; moved_out -= kBlock;
+                for (uint32_t i = lane; i < kBlock; i += 64u) {
+                    list[(tail + i) & kMask] = overflow[moved_out + i];
+                    if (TWO_LEVEL) list_copy[(tail + i) & kMask] = overflow_copy[moved_out + i];
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
+            uint32_t pops = head - tail < 64u ? head - tail : 64u;
+            if (head - tail + 3u * pops > kListMax) {
+                if (moved_out + kBlock <= overflow_cap) {               // make room: the oldest block leaves the ring
+                    for (uint32_t i = lane; i < kBlock; i += 64u) {
+                        overflow[moved_out + i] = list[(tail + i) & kMask];
+                        if (TWO_LEVEL) overflow_copy[moved_out + i] = list_copy[(tail + i) & kMask];
+                    }
+                    tail += kBlock; moved_out += kBlock;
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                } else {                                                // nowhere to go: fewer entries this turn
+                    pops = head - tail + 3u <= kListMax ? (kListMax - (head - tail)) / 3u : 1u;
+                    if (pops == 0u) pops = 1u;
+                }
+            }
             const bool mine = lane < pops;
-            const int32_t ref = mine ? list[size - 1u - lane] : kEmptyChild;
+            const int32_t ref = mine ? list[(head - 1u - lane) & kMask] : kEmptyChild;
             int32_t copy = -1;
-            if (TWO_LEVEL && mine) copy = list_copy[size - 1u - lane];
-            size -= pops;
+            if (TWO_LEVEL && mine) copy = list_copy[(head - 1u - lane) & kMask];
+            head -= pops;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
 
@@ -502,14 +531,14 @@ __global__ __launch_bounds__(kExtendThreads, TWO_LEVEL ? 6 : 4) void ptr_wf_exte
             const unsigned long long below = (1ull << lane) - 1ull;
             const uint32_t offset = (uint32_t)__popcll(b0 & below) + 2u * (uint32_t)__popcll(b1 & below) + 4u * (uint32_t)__popcll(b2 & below);
             const uint32_t total = (uint32_t)__popcll(b0) + 2u * (uint32_t)__popcll(b1) + 4u * (uint32_t)__popcll(b2);
-            if (size + total > kListMax) break;   // cannot happen while the header's stack bound holds; never write past the list
-            uint32_t at = size + offset;
-            if (TWO_LEVEL) for (uint32_t j = 0; j < n_push; j++) list_copy[at + j] = push_copy;
-            if (n_push > 3u) list[at++] = r3;
-            if (n_push > 2u) list[at++] = r2;
-            if (n_push > 1u) list[at++] = r1;
-            if (n_push > 0u) list[at++] = r0;
-            size += total;
+            if (head - tail + total > kListMax) break;   // ring and spill area both full (thousands of pending references): never write past them
+            uint32_t at = head + offset;
+            if (TWO_LEVEL) for (uint32_t j = 0; j < n_push; j++) list_copy[(at + j) & kMask] = push_copy;
+            if (n_push > 3u) list[at++ & kMask] = r3;
+            if (n_push > 2u) list[at++ & kMask] = r2;
+            if (n_push > 1u) list[at++ & kMask] = r1;
+            if (n_push > 0u) list[at++ & kMask] = r0;
+            head += total;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
         }

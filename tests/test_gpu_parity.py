@@ -403,6 +403,50 @@ def chain_layout(bundle, levels, claimed_depth):
     return np.concatenate([header, nodes.view(np.uint8).reshape(-1), tri.view(np.uint8).reshape(-1)])
 
 
+def fan_layout(bundle, depth):
+    """A complete 4-ary tree of `depth` levels of nodes whose every box is the whole scene: a ray that enters the scene box has to
+    visit all of it, and a breadth-first walk's frontier gets 4^depth wide.  Every triangle of the scene hangs off exactly one
+    leaf (spread evenly over the leaves; the others repeat the first record), so a reference lost on the way shows in the picture."""
+    _, _, tris0 = parse(bundle["flat"])
+    n = tris0.shape[0]
+    chain = chain_layout(bundle, 1, 3 * depth)
+    node = chain[64:128].view(np.float32).copy()
+    inner = (4 ** depth - 1) // 3
+    leaves = 4 ** depth
+    assert leaves >= n
+    stride = leaves // n
+    nodes = np.tile(node, (inner, 1))
+    ni = nodes.view(np.int32)
+    for k in range(inner):
+        for c in range(4):
+            child = 4 * k + 1 + c
+            if child < inner:
+                ni[k, 4 + c] = child
+            else:
+                leaf = child - inner
+                record = leaf // stride if leaf % stride == 0 and leaf // stride < n else 0
+                ni[k, 4 + c] = ~np.int32(record << 2)
+    header = chain[:64].copy()
+    header.view(np.uint32)[2:4] = [inner, n]
+    header.view(np.uint64)[3] = 64 + 64 * inner
+    return np.concatenate([header, nodes.view(np.uint8).reshape(-1), tris0.view(np.uint8).reshape(-1)])
+
+
+@pytest.mark.parametrize("depth", [5, 6])
+def test_wide_frontiers_in_the_wave_takeover(ctx, depth):
+    """341 / 1365 nodes that every ray must visit, 1024 / 4096 leaf references pending at once: the list of the wave that finishes
+    a ray together outgrows its LDS ring, so blocks of it move out to the spill area and back (and at depth 6 even that
+    fills up and the turns get narrower)."""
+    b = make_bundle("tiny", 0, 24, 16, max_bounce=2)
+    b = dict(b, flat=fan_layout(b, depth))
+    img, gs, cap, _ = gpu_frames(ctx, b, 2, "compute.wavefront", capture=True)
+    ref, _, aov = oracle_for(b, gs, 2, use_flat=True, aov=True)
+    assert len(np.unique(aov[0][..., 0])) > 8, "many different triangles are in view"
+    assert_same(cap[0], aov[0], "primitive ids")
+    assert_same(cap[1], aov[1], "hit distances")
+    assert_same(img, ref, "image")
+
+
 def test_deep_traversal_stacks(ctx):
     """42 levels x 3 pending entries: far past the 16 entries a lane keeps in LDS, so the spill area, the pops from it and the
     wave takeover's gather of a deep stack all run."""

@@ -127,3 +127,18 @@ def test_last_ray_of_a_wave_in_a_two_level_scene(ctx, turns):
     same(img, ref, f"image, alone_turns {turns}")
     ref2, _, _ = oracle_for(b, gs, 4, use_flat=True)
     same(img2, ref2, f"image of the overlapped frames, alone_turns {turns}")
+
+
+def test_wide_frontier_inside_placed_copies(ctx):
+    """Three copies of a 341-node tree that every ray must visit in full: the takeover's list (references and their copies)
+    outgrows the half-sized LDS ring of two-level scenes, so blocks of both arrays move out to the spill area and back."""
+    from test_gpu_parity import fan_layout
+    base = make_bundle("tiny", 0, 24, 16, max_bounce=2)
+    base = dict(base, flat=fan_layout(base, 5))
+    two, _ = two_level_bundle(base, assorted_transforms(base, 3), 40, 24, max_bounce=2)
+    img, gs, cap, _ = gpu_frames(ctx, two, 2, "compute.wavefront", capture=True)
+    ref, _, aov = oracle_for(two, gs, 2, use_flat=True, aov=True)
+    assert len(np.unique(aov[0][..., 0])) > 8, "many different triangles are in view"
+    same(cap[0], aov[0], "copy * triangles + primitive of the first two hits")
+    same(cap[1], aov[1], "hit distances")
+    same(img, ref, "image")
