@@ -102,6 +102,11 @@ int ptr_bvh_bind_instances(ptr_ctx* ctx, ptr_handle flat, ptr_handle instances);
  * to traverse than the host's binned-SAH one.  Equal-t ties are broken by primitive id (the host path can carry the reference's
  * visiting order instead).  Synchronous.  PTR_E_RANGE when the tree would be deeper than the traversal stack. */
 int ptr_bvh_build_flat(ptr_ctx* ctx, ptr_handle indices, ptr_handle positions, uint32_t triangle_count, ptr_handle* flat_out);
+/* Gives the triangles of a flattened layout (typically one from ptr_bvh_build_flat, whose ties go by primitive id) the tie-break
+ * ranks of the reference: on equal t the reference keeps the triangle it visits later (shaders/include/ray.h:153), and it visits
+ * leaves in the order of the threaded node array `threaded_nodes` (include/bvh.hpp:17-22, 2 * triangle_count - 1 records).
+ * After this call a dispatch over `flat` resolves ties like the megakernel over those nodes does.  Synchronous. */
+int ptr_bvh_flat_set_reference_ranks(ptr_ctx* ctx, ptr_handle flat, ptr_handle threaded_nodes, uint32_t triangle_count);
 
 int ptr_dispatch(ptr_ctx* ctx, const char* kernel, const uint8_t constants[64], uint32_t groups_x, uint32_t groups_y,
                  uint32_t groups_z);

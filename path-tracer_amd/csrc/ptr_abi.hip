@@ -966,6 +966,29 @@ int ptr_bvh_build_flat(ptr_ctx* c, ptr_handle indices, ptr_handle positions, uin
     return PTR_OK;
 }
 
+int ptr_bvh_flat_set_reference_ranks(ptr_ctx* c, ptr_handle flat, ptr_handle threaded_nodes, uint32_t triangle_count) {
+    if (!c) return PTR_E_INVALID;
+    BufferRec* f = find_buffer(c, flat);
+    BufferRec* t = find_buffer(c, threaded_nodes);
+    if (!f || !t) return fail(c, PTR_E_INVALID, "ptr_bvh_flat_set_reference_ranks: unknown flat or node buffer");
+    if (triangle_count == 0) return fail(c, PTR_E_INVALID, "ptr_bvh_flat_set_reference_ranks: no triangles");
+    int rc = bind_device(c); if (rc) return rc;
+    if ((rc = drain_frames(c))) return rc;
+    struct Header { uint32_t magic, version, node_count, triangle_count; uint64_t nodes_offset, triangles_offset; int32_t root; uint32_t max_depth; float bounds[6]; } hd;
+    if (f->size < sizeof hd) return fail(c, PTR_E_STATE, "ptr_bvh_flat_set_reference_ranks: blob shorter than its header");
+    PTR_HIP_CHECK(c, hipMemcpyAsync(&hd, f->ptr, sizeof hd, hipMemcpyDeviceToHost, c->stream));
+    PTR_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+    if (hd.magic != 0x46525450u || hd.version != 2u || (hd.triangles_offset & 63u) || hd.triangles_offset + (uint64_t)hd.triangle_count * 64 > f->size)
+        return fail(c, PTR_E_STATE, "ptr_bvh_flat_set_reference_ranks: not a flattened layout");
+    // the reference's builder emits 2N - 1 nodes for N triangles (src/bvh.cpp:48-86); a larger buffer's tail is not part of the tree
+    uint64_t nodes = t->size / sizeof(ptr::ThreadedNode);
+    if (nodes > 2ull * triangle_count - 1ull) nodes = 2ull * triangle_count - 1ull;
+    PTR_HIP_CHECK(c, ptr::apply_reference_ranks(c->stream, (const ptr::ThreadedNode*)t->ptr, (uint32_t)nodes,
+                                                (float4*)((uint8_t*)f->ptr + hd.triangles_offset), hd.triangle_count, triangle_count));
+    f->generation = ++c->write_epoch;
+    return PTR_OK;
+}
+
 int ptr_dispatch(ptr_ctx* c, const char* kernel, const uint8_t constants[64], uint32_t gx, uint32_t gy, uint32_t gz) {
     if (!c) return PTR_E_INVALID;
     if (!kernel || !constants) return fail(c, PTR_E_INVALID, "ptr_dispatch: null kernel name or constants");

@@ -81,6 +81,11 @@ size_t flat_build_blob_bytes(uint32_t triangle_count);
 // traversal_cost: cost of entering a node relative to one triangle test, for the leaf decision (surface-area heuristic).
 hipError_t build_flat_bvh(hipStream_t s, const SceneView& sv, uint32_t triangle_count, uint32_t vertex_count, void* blob, size_t blob_bytes, float traversal_cost, int* status);
 
+// Writes into the triangle records of a flattened layout the ranks of the reference's visiting order: the position of each
+// primitive's leaf among the leaves of the threaded node array (include/bvh.hpp:17-22).  Primitives the array does not hold
+// keep their rank.  Synchronous.
+hipError_t apply_reference_ranks(hipStream_t s, const ThreadedNode* nodes, uint32_t node_count, float4* records, uint32_t record_count, uint32_t triangle_count);
+
 // Contents check of the buffers a "compute" dispatch dereferences (ptr_kernels_validate.hip).  out4 (device, 4 words):
 // max vertex id, max material id, violations in the threaded nodes, violations in the flattened layout (and in the top
 // level over its copies, fv->top, when there is one).

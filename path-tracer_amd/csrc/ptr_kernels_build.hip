@@ -338,6 +338,27 @@ __global__ __launch_bounds__(256) void build_relayout(uint32_t count, const uint
     dst[3] = src[3];
 }
 
+// ---- ranks from the reference's threaded tree ---------------------------------------------------------------
+// The reference keeps the later-visited triangle on equal t (ray.h:153); its visiting order is the order of the leaves in
+// the threaded node array.  rank[primitive] = number of leaves before the primitive's own.
+__global__ __launch_bounds__(256) void rank_flags(const ThreadedNode* nodes, uint32_t node_count, uint32_t* flags) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i < node_count) flags[i] = nodes[i].primitive_id >= 0 ? 1u : 0u;
+}
+__global__ __launch_bounds__(256) void rank_scatter(const ThreadedNode* nodes, uint32_t node_count, const uint32_t* leaves_before, int32_t* rank_of_prim,
+                                                    uint32_t triangle_count) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= node_count) return;
+    const int32_t prim = nodes[i].primitive_id;
+    if (prim >= 0 && (uint32_t)prim < triangle_count) rank_of_prim[prim] = (int32_t)leaves_before[i];
+}
+__global__ __launch_bounds__(256) void rank_apply(float4* records, uint32_t record_count, const int32_t* rank_of_prim, uint32_t triangle_count) {
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    if (t >= record_count) return;
+    const int32_t prim = __float_as_int(records[4 * (size_t)t + 1].w);
+    if (prim >= 0 && (uint32_t)prim < triangle_count && rank_of_prim[prim] >= 0) records[4 * (size_t)t].w = __int_as_float(rank_of_prim[prim]);
+}
+
 struct FlatHeader {
     uint32_t magic, version, node_count, triangle_count;
     uint64_t nodes_offset, triangles_offset;
@@ -349,6 +370,31 @@ static_assert(sizeof(FlatHeader) == 64, "header is one 64-byte line");
 #define BUILD_CHECK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { cleanup(); return e_; } } while (0)
 
 }  // namespace
+
+hipError_t apply_reference_ranks(hipStream_t s, const ThreadedNode* nodes, uint32_t node_count, float4* records, uint32_t record_count, uint32_t triangle_count) {
+    if (node_count == 0 || record_count == 0 || triangle_count == 0) return hipSuccess;
+    uint32_t *flags = nullptr, *before = nullptr;
+    int32_t* rank_of_prim = nullptr;
+    void* temp = nullptr;
+    auto cleanup = [&]() { (void)hipFree(flags); (void)hipFree(before); (void)hipFree(rank_of_prim); (void)hipFree(temp); };
+    hipError_t e;
+    if ((e = hipMalloc((void**)&flags, (size_t)node_count * 4)) != hipSuccess) { cleanup(); return e; }
+    if ((e = hipMalloc((void**)&before, (size_t)node_count * 4)) != hipSuccess) { cleanup(); return e; }
+    if ((e = hipMalloc((void**)&rank_of_prim, (size_t)triangle_count * 4)) != hipSuccess) { cleanup(); return e; }
+    if ((e = hipMemsetAsync(rank_of_prim, 0xff, (size_t)triangle_count * 4, s)) != hipSuccess) { cleanup(); return e; }   // -1: not in the tree, rank untouched
+    const uint32_t nb = (node_count + 255u) / 256u;
+    hipLaunchKernelGGL(rank_flags, dim3(nb), dim3(256), 0, s, nodes, node_count, flags);
+    size_t bytes = 0;
+    if ((e = hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, flags, before, (int)node_count, s)) != hipSuccess) { cleanup(); return e; }
+    if ((e = hipMalloc(&temp, bytes ? bytes : 16)) != hipSuccess) { cleanup(); return e; }
+    if ((e = hipcub::DeviceScan::ExclusiveSum(temp, bytes, flags, before, (int)node_count, s)) != hipSuccess) { cleanup(); return e; }
+    hipLaunchKernelGGL(rank_scatter, dim3(nb), dim3(256), 0, s, nodes, node_count, before, rank_of_prim, triangle_count);
+    hipLaunchKernelGGL(rank_apply, dim3((record_count + 255u) / 256u), dim3(256), 0, s, records, record_count, rank_of_prim, triangle_count);
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    cleanup();
+    return e;
+}
 
 size_t flat_build_blob_bytes(uint32_t triangle_count) {
     // header + at most one wide node per two triangles' worth of leaves... a wide node has >= 2 children, so there are

@@ -72,6 +72,7 @@ def lib():
         "ptr_profile_names": [vp, C.c_char_p, sz],
         "ptr_device_function": [vp, C.c_char_p, vp, u32, vp, u32, u32],
         "ptr_bvh_build_flat": [vp, u32, u32, u32, P(u32)],
+        "ptr_bvh_flat_set_reference_ranks": [vp, u32, u32, u32],
     }
     for name, args in sigs.items():
         fn = getattr(L, name)
@@ -88,7 +89,7 @@ ABI_SYMBOLS = ["ptr_ctx_create", "ptr_ctx_destroy", "ptr_ctx_set_stream", "ptr_l
                "ptr_image_create", "ptr_image_wrap", "ptr_image_destroy", "ptr_image_upload", "ptr_image_read",
                "ptr_image_index", "ptr_sampler_index", "ptr_image_address", "ptr_bvh_bind_flat", "ptr_bvh_bind_instances", "ptr_dispatch",
                "ptr_set_partition", "ptr_set_sample_partition", "ptr_set_option", "ptr_set_capture", "ptr_stats_enable", "ptr_stats_read", "ptr_profile_enable",
-               "ptr_profile_read", "ptr_profile_names", "ptr_device_function", "ptr_bvh_build_flat"]
+               "ptr_profile_read", "ptr_profile_names", "ptr_device_function", "ptr_bvh_build_flat", "ptr_bvh_flat_set_reference_ranks"]
 
 
 class Context:
@@ -190,6 +191,10 @@ class Context:
         h = C.c_uint32()
         self._check(self._L.ptr_bvh_build_flat(self.handle, indices_buffer.handle, positions_buffer.handle, triangle_count, C.byref(h)))
         return Buffer.adopt(self, h.value, 64 + 128 * triangle_count)
+
+    def flat_set_reference_ranks(self, flat_buffer, node_buffer, triangle_count):
+        """Tie-break ranks of the reference's visiting order (the leaf order of the threaded nodes) for a flattened layout."""
+        self._check(self._L.ptr_bvh_flat_set_reference_ranks(self.handle, flat_buffer.handle, node_buffer.handle, triangle_count))
 
     def bind_flat(self, node_buffer, flat_buffer):
         self._check(self._L.ptr_bvh_bind_flat(self.handle, node_buffer.handle, flat_buffer.handle if flat_buffer is not None else 0))

@@ -101,3 +101,47 @@ def test_the_same_scene_gives_the_same_blob(ctx):
     assert np.array_equal(a[:used], b[:used]), "header and nodes"
     t0 = h["triangles_offset"]
     assert np.array_equal(a[t0:t0 + 64 * h["triangle_count"]], b[t0:t0 + 64 * h["triangle_count"]]), "triangle records"
+
+
+def test_reference_ranks_for_a_gpu_built_layout(ctx):
+    """ptr_bvh_flat_set_reference_ranks: the records of a GPU-built layout get the reference's visiting order (the leaf order of the
+    threaded nodes) as tie-break ranks.  The scene holds a coincident twin of its largest triangle with another material, so every
+    hit on the pair is an equal-t tie that the ranks decide; the wavefront path then agrees with the oracle walking the same blob
+    bit for bit, and with the megakernel over the reference's tree."""
+    from path_tracer_amd import hip, host
+    sc = scenes.tiny_scene(4)
+    P = np.asarray(sc["positions"], np.float32).reshape(-1, 3)
+    I = np.asarray(sc["indices"], np.uint32).reshape(-1, 3)
+    tri = P[I & np.uint32(0x00FFFFFF)]
+    big = int(np.argmax(np.linalg.norm(np.cross(tri[:, 1] - tri[:, 0], tri[:, 2] - tri[:, 0]), axis=1)))
+    mat = ((int(I[big, 0]) >> 24) << 16) | ((int(I[big, 1]) >> 24) << 8) | (int(I[big, 2]) >> 24)
+    other = (mat + 1) % len(sc["materials"])
+    twin = (I[big] & np.uint32(0x00FFFFFF)) | np.array([(other >> 16) & 0xFF, (other >> 8) & 0xFF, other & 0xFF], np.uint32) << np.uint32(24)
+    indices = np.concatenate([I, twin[None, :]]).astype(np.uint32)
+    sc = dict(sc, indices=indices.reshape(-1), triangles=np.concatenate([tri.reshape(-1, 9), tri[big].reshape(1, 9)]).astype(np.float32))
+    n = sc["triangles"].shape[0]
+    nodes = host.bvh_build(sc["triangles"])
+    ranks = host.bvh_visit_ranks(nodes, n)
+    assert not np.array_equal(ranks, np.arange(n)), "the visiting order is not the primitive order"
+    c = sc["camera"]
+    W, H = 64, 40
+    meta = scenes.pack_metadata(host.camera(c["pos"], c["target"], c["v_fov"], W / H, c["aperture"], c["focus"]), W, H, max_bounce=3)
+    b = dict(sc, nodes=nodes, meta=meta, width=W, height=H)
+    gs = hip.GpuScene(ctx, b, nodes, None, meta)
+    gs.wire(ctx.create_compute_renderpass())
+    flat_buffer = ctx.build_flat(gs.indices_buffer, gs.positions_buffer, n)
+    check_flat_layout(flat_buffer.read(np.uint8), sc["triangles"], np.arange(n))
+    ctx.flat_set_reference_ranks(flat_buffer, gs.bvh_buffer, n)
+    blob = flat_buffer.read(np.uint8)
+    check_flat_layout(blob, sc["triangles"], ranks)                      # every record now carries the visiting rank of its primitive
+    mega, _, capm, _ = gpu_frames(ctx, b, 2, "compute.megakernel", gpu_scene=gs, capture=True)
+    ctx.bind_flat(gs.bvh_buffer, flat_buffer)
+    img, _, cap, _ = gpu_frames(ctx, b, 2, "compute.wavefront", gpu_scene=gs, capture=True)
+    ref, _, aov = oracle_frames(dict(b, flat=blob), 2, use_flat=True, materials=gs.materials_host, textures=gs.texture_table, aov=True)
+    assert np.array_equal(img, ref) and np.array_equal(cap[0], aov[0]) and np.array_equal(cap[1], aov[1])
+    pair = np.isin(capm[0][..., 0], [big, n - 1])
+    assert pair.mean() > 0.02, "the coincident pair is in view"
+    assert np.array_equal(cap[0][..., 0][pair], capm[0][..., 0][pair]), "the same twin wins the ties as in the reference's walk"
+    assert (cap[0] != capm[0]).sum() <= 4                                # the declared tie classes between the two trees, if any
+    with pytest.raises(hip.HipError):
+        ctx.flat_set_reference_ranks(gs.bvh_buffer, gs.bvh_buffer, n)    # not a flattened layout
