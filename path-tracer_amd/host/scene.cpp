@@ -108,6 +108,9 @@ scene::scene(const camera& cam, uint32_t width, uint32_t height, const scene_sou
         hiprenderer::check(ptr_bvh_build_flat(hiprenderer::api, indices_buffer->device_buffer, positions_buffer->device_buffer, (uint32_t)triangle_count, &built),
                            "ptr_bvh_build_flat");
         flat_bvh_buffer = new Buffer(built, 64 + 128 * triangle_count);
+        // equal-t ties as the reference's walk resolves them: ranks from the leaf order of the threaded nodes
+        hiprenderer::check(ptr_bvh_flat_set_reference_ranks(hiprenderer::api, built, bvh_buffer->device_buffer, (uint32_t)triangle_count),
+                           "ptr_bvh_flat_set_reference_ranks");
         hiprenderer::check(ptr_bvh_bind_flat(hiprenderer::api, bvh_buffer->device_buffer, flat_bvh_buffer->device_buffer), "ptr_bvh_bind_flat");
         bvh_mode += " + gpu radix tree";
     } else if (flatten_bvh) {
