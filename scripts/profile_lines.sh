@@ -9,3 +9,5 @@ run line_98M --instances 6x6
 run line_98M_gpu_bvh --instances 6x6 --bvh gpu
 run line_two_level --instances 6x6 --two-level
 run line_two_level_gpu_bvh --instances 6x6 --two-level --bvh gpu
+run line_4k --width 3840 --height 2160 --steps 20
+run line_720p --width 1280 --height 720
