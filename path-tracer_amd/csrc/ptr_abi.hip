@@ -121,6 +121,10 @@ struct ptr_ctx {
     uint8_t* stage = nullptr;              // kStageSlots x kShadowLimit bytes, pinned
     hipEvent_t stage_done[kStageSlots] = {};
     int stage_next = 0;
+    // one pinned, device-visible word the traversal kernel sets when it had to give up on a ray (only possible with the
+    // scene checks off and a layout header that understates its stack need); reported by the next ptr_sync / ptr_dispatch
+    volatile uint32_t* fault = nullptr;
+    uint32_t* fault_device = nullptr;
 };
 
 namespace {
@@ -231,6 +235,14 @@ bool frame_reads(const ptr_ctx* c, ptr_handle h) {
         if (slot.in_flight)
             for (ptr_handle r : slot.reads) if (r == h && h != 0) return true;
     return false;
+}
+// A traversal kernel that had to give up on a ray says so in the context's host-visible fault word.
+int take_fault(ptr_ctx* c) {
+    if (c->fault && *c->fault != 0u) {
+        *c->fault = 0u;
+        return fail(c, PTR_E_RANGE, "an earlier frame's traversal ran out of list space (the layout header understates the tree's stack need): that frame's image is incomplete");
+    }
+    return PTR_OK;
 }
 int ensure_slot(ptr_ctx* c, ptr_ctx::FrameSlot& slot) {
     if (slot.stream) return PTR_OK;
@@ -435,6 +447,10 @@ int dispatch_compute(ptr_ctx* c, const uint8_t constants[64], uint32_t gx, uint3
     if (meta.width == 0 || meta.height == 0) return fail(c, PTR_E_STATE, "scene metadata: zero width/height");
     if (meta.downscale_factor < 1) return fail(c, PTR_E_STATE, "scene metadata: downscale_factor < 1");
     if (meta.sample_index == 0) return fail(c, PTR_E_STATE, "scene metadata: sample_index must start at 1 (1/sample_index weights the frame)");
+    // pixel and queue-slot numbers are 32-bit products of these two
+    if (meta.width > 65535u || meta.height > 65535u || (uint64_t)meta.width * meta.height > (1ull << 28))
+        return fail(c, PTR_E_RANGE, "scene metadata: %u x %u is more than the path addresses (65535 per side, 2^28 pixels)", meta.width, meta.height);
+    if ((rc = take_fault(c))) return rc;
 
     static const char* names[7] = { "scene", "bvh", "indices", "positions", "normals", "uvs", "materials" };
     ptr_handle handles[7] = {};
@@ -470,7 +486,18 @@ int dispatch_compute(ptr_ctx* c, const uint8_t constants[64], uint32_t gx, uint3
 
     BufferRec* bvh_buf = &c->buffers[handles[1]];
     BufferRec* flat_buf = bvh_buf->flat ? find_buffer(c, bvh_buf->flat) : nullptr;
-    const bool wavefront = force == 2 || (force == 0 && flat_buf != nullptr);
+    bool wavefront = force == 2 || (force == 0 && flat_buf != nullptr);
+    if (meta.debug_bvh == 1u && wavefront) {
+        // compute.comp:274-275: the heat-map counts the boxes of the THREADED tree a primary ray enters (ray.h:80-103); it is
+        // defined on that tree only, so the frame goes to the kernel that walks it, whatever layout is bound beside it
+        const uint64_t triangles = ((uint64_t)(uintptr_t)c->buffers[handles[2]].ptr + c->buffers[handles[2]].size - k.addr[2]) / (4u * (uint64_t)c->opt_index_words);
+        const uint64_t node_bytes = (uint64_t)(uintptr_t)bvh_buf->ptr + bvh_buf->size - k.addr[1];
+        if (triangles == 0 || node_bytes / sizeof(ptr::ThreadedNode) < 2 * triangles - 1)
+            return fail(c, PTR_E_UNSUPPORTED, "debug_bvh: the heat-map counts boxes of the threaded bvh nodes (2N-1 records for N triangles); the bvh buffer of this dispatch holds no such tree");
+        if (flat_buf && flat_buf->instances)
+            return fail(c, PTR_E_UNSUPPORTED, "debug_bvh: not defined for placed copies (the threaded tree has no instancing)");
+        wavefront = false;
+    }
     if (c->stats_on) c->stats_frames++;
 
     if (!wavefront) {
@@ -558,6 +585,7 @@ int dispatch_compute(ptr_ctx* c, const uint8_t constants[64], uint32_t gx, uint3
     const uint32_t padded = ((meta.width + 7u) / 8u) * ((meta.height + 7u) / 8u + c->part_stripe / 8u) * 64u;
     if ((rc = ensure_scratch(c, slot, padded > meta.width * meta.height ? padded : meta.width * meta.height, fv.max_depth))) return rc;
     slot.scratch.alone_turns = (uint32_t)c->opt_extend_alone_turns;
+    slot.scratch.fault = c->fault_device;
     const ptr::WavefrontScratch& w = slot.scratch;
 
     if (overlap) {
@@ -631,6 +659,9 @@ int ptr_ctx_create(int device, ptr_ctx** out) {
     if ((e = hipHostMalloc((void**)&c->stage, (size_t)ptr_ctx::kStageSlots * kShadowLimit, hipHostMallocDefault)) != hipSuccess) return bail("hipHostMalloc(staging ring)", e);
     for (int i = 0; i < ptr_ctx::kStageSlots; i++)
         if ((e = hipEventCreateWithFlags(&c->stage_done[i], hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate(staging ring)", e);
+    if ((e = hipHostMalloc((void**)&c->fault, 64, hipHostMallocMapped)) != hipSuccess) return bail("hipHostMalloc(fault word)", e);
+    *c->fault = 0u;
+    if ((e = hipHostGetDevicePointer((void**)&c->fault_device, (void*)c->fault, 0)) != hipSuccess) return bail("hipHostGetDevicePointer(fault word)", e);
     if ((e = hipMalloc((void**)&c->d_stats, 8 * sizeof(unsigned long long))) != hipSuccess) return bail("hipMalloc(stats)", e);
     if ((e = hipMemset(c->d_stats, 0, 8 * sizeof(unsigned long long))) != hipSuccess) return bail("hipMemset(stats)", e);
     *out = c;
@@ -657,6 +688,7 @@ int ptr_ctx_destroy(ptr_ctx* c) {
     if (c->d_stats) (void)hipFree(c->d_stats);
     for (auto e : c->stage_done) if (e) (void)hipEventDestroy(e);
     if (c->stage) (void)hipHostFree(c->stage);
+    if (c->fault) (void)hipHostFree((void*)c->fault);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
     return PTR_OK;
@@ -690,7 +722,7 @@ int ptr_sync(ptr_ctx* c) {
     PTR_HIP_CHECK(c, hipStreamSynchronize(c->stream));
     // whatever the caller wrote into device memory by other means before this point is ordered before later frames
     c->shared_epoch = ++c->write_epoch;
-    return PTR_OK;
+    return take_fault(c);
 }
 
 int ptr_buffer_create(ptr_ctx* c, size_t size, ptr_handle* out) {
@@ -845,7 +877,7 @@ int ptr_image_read(ptr_ctx* c, ptr_handle h, void* texels) {
     int rc = bind_device(c); if (rc) return rc;
     PTR_HIP_CHECK(c, hipMemcpyAsync(texels, im->ptr, (size_t)im->w * im->h * texel_size(im->format), hipMemcpyDeviceToHost, c->stream));
     PTR_HIP_CHECK(c, hipStreamSynchronize(c->stream));
-    return PTR_OK;
+    return take_fault(c);
 }
 
 int ptr_device_function(ptr_ctx* c, const char* name, const uint32_t* in, uint32_t in_words, uint32_t* out, uint32_t out_words,
@@ -1026,7 +1058,7 @@ int ptr_dispatch(ptr_ctx* c, const char* kernel, const uint8_t constants[64], ui
 int ptr_set_partition(ptr_ctx* c, uint32_t rank, uint32_t world, uint32_t stripe_rows) {
     if (!c) return PTR_E_INVALID;
     if (world == 0 || rank >= world) return fail(c, PTR_E_INVALID, "ptr_set_partition: rank %u / world %u", rank, world);
-    if (stripe_rows == 0 || (stripe_rows & 7u)) return fail(c, PTR_E_INVALID, "ptr_set_partition: stripe_rows must be a positive multiple of 8");
+    if (stripe_rows == 0 || (stripe_rows & 7u) || stripe_rows > 65536u) return fail(c, PTR_E_INVALID, "ptr_set_partition: stripe_rows must be a positive multiple of 8, 65536 at most");
     c->part_rank = rank; c->part_world = world; c->part_stripe = stripe_rows;
     return PTR_OK;
 }

@@ -41,6 +41,7 @@ struct WavefrontScratch {
     float4* samples;        // per pixel: the sample's colour (w unused)
     uint32_t* counters;     // [0..15]: live paths entering bounce b; [16..31]: fetch cursors of the extend kernel
     int32_t* stack_spill;   // traversal stack overflow area of the persistent extend grid
+    uint32_t* fault;        // host-visible word (pinned memory): set to 1 when a traversal ran out of list space
     uint32_t capacity;
     uint32_t extend_blocks; // persistent grid size
     uint32_t spill_entries; // per-lane entries of stack_spill (sized for the deepest tree bound so far)

@@ -27,13 +27,15 @@ __global__ __launch_bounds__(256) void validate_indices(SceneView sv, uint32_t t
     if (threadIdx.x < 2) atomicMax(&out[threadIdx.x], red[threadIdx.x]);
 }
 
-// Threaded nodes (include/bvh.hpp:17-22): next_id in [-1, n), primitive_id in [-1, triangles), an inner node has a
-// successor (its left child is the next record).  out[2] = violations.
+// Threaded nodes (include/bvh.hpp:17-22): next_id is -1 or a LATER record (the builder numbers nodes depth first,
+// src/bvh.cpp:264-279, so a skip link always points forward; with that, every step of the stackless walk moves to a higher
+// index and the walk ends after at most n steps -- a backward or self link would loop forever), primitive_id in
+// [-1, triangles), an inner node has a successor (its left child is the next record).  out[2] = violations.
 __global__ __launch_bounds__(256) void validate_threaded(const ThreadedNode* nodes, uint32_t node_count, uint32_t triangle_count, uint32_t* out) {
     uint32_t bad = 0u;
     for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < node_count; i += gridDim.x * 256u) {
         const int32_t next = nodes[i].next_id, prim = nodes[i].primitive_id;
-        if (next < -1 || (next >= 0 && (uint32_t)next >= node_count)) bad++;
+        if (next < -1 || (next >= 0 && ((uint32_t)next >= node_count || (uint32_t)next <= i))) bad++;
         if (prim < -1 || (prim >= 0 && (uint32_t)prim >= triangle_count)) bad++;
         if (prim == -1 && i + 1u >= node_count) bad++;
     }

@@ -411,6 +411,14 @@ __global__ __launch_bounds__(kExtendThreads, TWO_LEVEL ? 6 : 4) void ptr_wf_exte
         int32_t* overflow = w.stack_spill + (size_t)global_wave * w.spill_entries * 64u;
         const uint32_t overflow_cap = ((w.spill_entries * 64u) / (TWO_LEVEL ? 2u : 1u)) / kBlock * kBlock;
         int32_t* overflow_copy = overflow + overflow_cap;              // TWO_LEVEL: the copies of the entries moved out
+        // No pending reference is ever dropped.  A turn that pops p entries appends at most 4p, so the ring grows by at most
+        // 3p.  Turns are sized so that the ring stays within `limit` = kListMax - (fv.max_depth + 3) entries; once it is that
+        // full and the spill area is full too, turns pop ONE entry, the newest: the list then behaves as the stack of a
+        // depth-first walk below that entry, which holds at most fv.max_depth + 1 references at once (the bound the layout
+        // header states for a lane's stack, checked against the tree before the first dispatch; + 1 because the nearest child
+        // is stacked here too), and the ring is back to its earlier length when that subtree is done.  So the ring never
+        // exceeds limit + fv.max_depth + 1 < kListMax, whatever the width of the ray's frontier.
+        const uint32_t limit = kListMax - (fv.max_depth + 3u);
         uint32_t tail = 0u, head = size, moved_out = 0u;
         while (head != tail || moved_out != 0u) {
             if (head - tail < 64u && moved_out != 0u) {                // bring the newest block back below the ring
@@ -423,20 +431,17 @@ __global__ __launch_bounds__(kExtendThreads, TWO_LEVEL ? 6 : 4) void ptr_wf_exte
                 __builtin_amdgcn_wave_barrier();
             }
             uint32_t pops = head - tail < 64u ? head - tail : 64u;
-            if (head - tail + 3u * pops > kListMax) {
-                if (moved_out + kBlock <= overflow_cap) {               // make room: the oldest block leaves the ring
-                    for (uint32_t i = lane; i < kBlock; i += 64u) {
-                        overflow[moved_out + i] = list[(tail + i) & kMask];
-                        if (TWO_LEVEL) overflow_copy[moved_out + i] = list_copy[(tail + i) & kMask];
-                    }
-                    tail += kBlock; moved_out += kBlock;
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                } else {                                                // nowhere to go: fewer entries this turn
-                    pops = head - tail + 3u <= kListMax ? (kListMax - (head - tail)) / 3u : 1u;
-                    if (pops == 0u) pops = 1u;
+            if (head - tail + 3u * pops > limit && head - tail >= kBlock + 64u && moved_out + kBlock <= overflow_cap) {
+                for (uint32_t i = lane; i < kBlock; i += 64u) {        // make room: the oldest block leaves the ring
+                    overflow[moved_out + i] = list[(tail + i) & kMask];
+                    if (TWO_LEVEL) overflow_copy[moved_out + i] = list_copy[(tail + i) & kMask];
                 }
+                tail += kBlock; moved_out += kBlock;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
             }
+            if (head - tail + 3u * pops > limit)                        // still too full: a narrower turn, down to depth first
+                pops = head - tail + 3u <= limit ? (limit - (head - tail)) / 3u : 1u;
             const bool mine = lane < pops;
             const int32_t ref = mine ? list[(head - 1u - lane) & kMask] : kEmptyChild;
             int32_t copy = -1;
@@ -531,7 +536,13 @@ __global__ __launch_bounds__(kExtendThreads, TWO_LEVEL ? 6 : 4) void ptr_wf_exte
             const unsigned long long below = (1ull << lane) - 1ull;
             const uint32_t offset = (uint32_t)__popcll(b0 & below) + 2u * (uint32_t)__popcll(b1 & below) + 4u * (uint32_t)__popcll(b2 & below);
             const uint32_t total = (uint32_t)__popcll(b0) + 2u * (uint32_t)__popcll(b1) + 4u * (uint32_t)__popcll(b2);
-            if (head - tail + total > kListMax) break;   // ring and spill area both full (thousands of pending references): never write past them
+            if (head - tail + total > kListMax) {
+                // Unreachable for a layout whose header states its true stack need (see `limit` above); a caller who turned
+                // the scene checks off can get here with a header that understates it.  Never write past the ring: report
+                // through the host-visible fault word (the next ptr_sync / ptr_dispatch fails with PTR_E_RANGE) and stop.
+                if (lane == 0u) *w.fault = 1u;
+                break;
+            }
             uint32_t at = head + offset;
             if (TWO_LEVEL) for (uint32_t j = 0; j < n_push; j++) list_copy[(at + j) & kMask] = push_copy;
             if (n_push > 3u) list[at++ & kMask] = r3;

@@ -108,6 +108,26 @@ def test_headless_driver_gpu_built_bvh(tmp_path):
     assert differing <= 3, differing
 
 
+def test_headless_driver_debug_bvh_heatmap(tmp_path):
+    """--debug-bvh 1 with the default pipeline (the scene class always binds a flattened layout): the reference's heat-map of
+    the threaded tree (compute.comp:274-275), not a normal frame."""
+    W, H = 72, 40
+    b = make_bundle("atrium", 3000, W, H, max_bounce=4, debug_bvh=1)
+    scene_file = str(tmp_path / "scene.ptrscene")
+    out_file = str(tmp_path / "out.pfm")
+    scenes.save_ptrscene(b, scene_file)
+    c = b["camera"]
+    cmd = [HEADLESS, "--scene", scene_file, "--width", str(W), "--height", str(H), "--spp", "1", "--max-bounce", "4", "--debug-bvh", "1",
+           "--out", out_file, "--pos", *map(str, c["pos"]), "--target", *map(str, c["target"]),
+           "--fov", str(c["v_fov"]), "--aperture", str(c["aperture"]), "--focus", str(c["focus"])]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    ref, _, _ = oracle_frames(b, 1)
+    img = read_ptrf(out_file)
+    assert np.array_equal(img, ref), f"{int((np.abs(img - ref).max(axis=2) > 0).sum())} pixels differ\n{r.stderr}"
+    assert img[..., 0].max() > 0 and img[..., 1].max() == 0
+
+
 def test_headless_reports_errors():
     r = subprocess.run([HEADLESS, "--scene", "/nonexistent.ptrscene"], capture_output=True, text=True, timeout=60)
     assert r.returncode == 1 and "cannot open" in r.stderr

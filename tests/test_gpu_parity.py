@@ -214,6 +214,11 @@ def test_bad_scene_contents_fail_the_dispatch_instead_of_faulting(ctx):
     bad = nodes.copy(); bad[5, 3] = np.uint32(len(nodes) + 10)                                      # a skip link past the end
     gs.bvh_buffer.write(bad)
     expect_failure("compute.megakernel", "bvh nodes")
+    # a skip link that points backwards (or at its own node) is in range, yet the stackless walk would never end
+    for at, to in ((5, 5), (9, 2)):
+        bad = nodes.copy(); bad[at, 3] = np.uint32(to)
+        gs.bvh_buffer.write(bad)
+        expect_failure("compute.megakernel", "bvh nodes")
     gs.bvh_buffer.write(nodes)
 
     flat = np.asarray(b["flat"], np.uint8).copy()
@@ -447,6 +452,21 @@ def test_wide_frontiers_in_the_wave_takeover(ctx, depth):
     assert_same(img, ref, "image")
 
 
+def test_a_frontier_wider_than_ring_and_spill_area_loses_nothing(ctx):
+    """Depth 7: 16 384 leaf references pending at once, four times what the wave's LDS ring (1024) and its spill area (3072)
+    hold together.  The takeover then narrows its turns, down to one reference per turn (a depth-first walk, whose need the
+    layout header bounds), instead of dropping what does not fit: every hit still equals the oracle's."""
+    b = make_bundle("tiny", 0, 24, 16, max_bounce=2)
+    b = dict(b, flat=fan_layout(b, 7))
+    img, gs, cap, _ = gpu_frames(ctx, b, 2, "compute.wavefront", capture=True)
+    ref, _, aov = oracle_for(b, gs, 2, use_flat=True, aov=True)
+    assert len(np.unique(aov[0][..., 0])) > 8, "many different triangles are in view"
+    assert_same(cap[0], aov[0], "primitive ids")
+    assert_same(cap[1], aov[1], "hit distances")
+    assert_same(img, ref, "image")
+    ctx.sync()                                                      # and no fault was raised on the way
+
+
 def test_deep_traversal_stacks(ctx):
     """42 levels x 3 pending entries: far past the 16 entries a lane keeps in LDS, so the spill area, the pops from it and the
     wave takeover's gather of a deep stack all run."""
@@ -487,11 +507,24 @@ def test_layout_header_that_understates_its_stack_is_refused(ctx):
 
 
 def test_debug_bvh_heatmap(ctx):
+    """compute.comp:274-275 / ray.h:80-103: boxes of the threaded tree a primary ray enters, x 0.001, in red.  The counts are
+    defined on that tree, so every dispatch name gives the same picture -- also "compute" with a flattened layout bound
+    (what the scene class always does), which must not quietly render a normal frame."""
+    from path_tracer_amd import hip
     b = make_bundle("atrium", 3000, 64, 40, debug_bvh=1)
     img, gs, _, _ = gpu_frames(ctx, b, 1, "compute.megakernel")
     ref, _, _ = oracle_for(b, gs, 1)
     assert_same(img, ref, "debug_bvh")
     assert img[..., 0].max() > 0 and img[..., 1].max() == 0
+    for pipeline in ("compute", "compute.wavefront"):
+        assert_same(gpu_frames(ctx, b, 1, pipeline, gpu_scene=gs)[0], ref, f"debug_bvh through {pipeline} with a flattened layout bound")
+    normal = gpu_frames(ctx, dict(b, meta=make_bundle("atrium", 3000, 64, 40)["meta"]), 1, "compute", gpu_scene=gs)[0]
+    assert not np.array_equal(normal, ref)                         # the flag is what made the difference
+    # no threaded tree to count on (a placeholder node buffer, as the large-scene benchmark uses): an error, not a picture
+    placeholder = np.zeros((1, 8), np.uint32); placeholder[0, 3] = 0xFFFFFFFF
+    gs2 = hip.GpuScene(ctx, b, placeholder, b["flat"], b["meta"])
+    with pytest.raises(hip.HipError, match="debug_bvh"):
+        hip.FrameLoop(ctx, gs2, 64, 40, "compute").frame()
 
 
 def test_tonemapping_kernel(ctx):
@@ -556,6 +589,10 @@ def test_error_paths(ctx):
     gs.update_meta(sample_index=0)
     with pytest.raises(hip.HipError, match="sample_index"):
         ctx.dispatch("compute", loop.renderpass.constants, 5, 3, 1)
+    gs.update_meta(sample_index=1, width=65536, height=65537)     # products of these index the queues: no 32-bit wrap-around
+    with pytest.raises(hip.HipError, match="more than the path addresses"):
+        ctx.dispatch("compute", loop.renderpass.constants, 5, 3, 1)
+    gs.update_meta(width=32, height=16)
     with pytest.raises(hip.HipError, match="outside"):
         gs.scene_buffer.write(np.zeros(8, np.uint8), 316, 8)
     with pytest.raises(hip.HipError, match="LINEAR"):
