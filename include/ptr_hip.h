@@ -111,6 +111,23 @@ int ptr_bvh_flat_set_reference_ranks(ptr_ctx* ctx, ptr_handle flat, ptr_handle t
 int ptr_dispatch(ptr_ctx* ctx, const char* kernel, const uint8_t constants[64], uint32_t groups_x, uint32_t groups_y,
                  uint32_t groups_z);
 
+/* The same "compute" dispatch for callers that cannot allocate device memory -- code under HIP graph capture, tight serving
+ * loops, harnesses that forbid hipMalloc.  It has no counterpart in the reference.  ptr_dispatch keeps the queues, hit
+ * records, counters and traversal-stack spill area of the wavefront pipeline in scratch it allocates (and re-allocates when a
+ * larger frame or a deeper tree comes along); this entry point keeps them in ONE fixed 34 MB array per GPU that is part of the
+ * library's device image and stays until the process ends, and calls no hipMalloc / hipFree / stream or event creation on the
+ * way.  Same arguments, same images bit for bit.  Limits (PTR_E_RANGE beyond them): a frame of at most 163 840 queue slots
+ * -- ceil(width/8) * (ceil(height/8) + stripe_rows/8) * 64, e.g. 512 x 288 -- and a flattened layout whose header asks for a
+ * traversal stack of at most 61 entries.  What ptr_dispatch does once per upload with allocations is not repeated here: the
+ * scene buffers must have passed the contents check in an earlier ptr_dispatch (PTR_E_STATE otherwise, unless
+ * "scene.validate" is 0), and the per-triangle shading records are used when that earlier dispatch built them (else the shade
+ * step gathers per hit, same results).  The frame runs start to end on the context's stream ("frames.in_flight" does not
+ * apply; no per-kernel profile events), on a smaller persistent traversal grid than ptr_dispatch uses.  Every call on a GPU
+ * shares that GPU's array: calls that can overlap on one GPU (two contexts, or one context moved between streams without
+ * a ptr_sync) race.  kernel: "compute", "compute.megakernel" (uses no scratch at all) or "compute.wavefront". */
+int ptr_dispatch_static(ptr_ctx* ctx, const char* kernel, const uint8_t constants[64], uint32_t groups_x, uint32_t groups_y,
+                        uint32_t groups_z);
+
 /* ---- multi-GPU tile partition (no counterpart in the single-GPU reference): this context renders only
  *      the 8-row-aligned stripes s with s % world == rank, stripe = stripe_rows image rows.
  *      world = 1 restores the whole frame. ---- */

@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -125,6 +126,7 @@ struct ptr_ctx {
     // scene checks off and a layout header that understates its stack need); reported by the next ptr_sync / ptr_dispatch
     volatile uint32_t* fault = nullptr;
     uint32_t* fault_device = nullptr;
+    ptr::WavefrontScratch static_scratch{};   // views into this GPU's fixed scratch array (ptr_dispatch_static)
 };
 
 namespace {
@@ -144,6 +146,36 @@ int fail(ptr_ctx* c, int code, const char* fmt, ...) {
         hipError_t e_ = (expr);                                                                        \
         if (e_ != hipSuccess) return fail(ctx, PTR_E_HIP, "%s: %s", #expr, hipGetErrorString(e_));     \
     } while (0)
+
+// ---- the scratch of ptr_dispatch_static: one fixed array per GPU instead of allocations ----
+// Queues, hit records, per-pixel samples, counters and the traversal-stack spill area of ONE frame, laid out like the
+// allocated scratch of a frame slot.  Each GPU holds its own copy of the array at its own address; host code must use
+// that address (looked up once per device, below), never the array's name.
+constexpr uint32_t kStaticPaths = 160u * 1024u;   // queue slots (whole 8x8 tiles of the frame plus one stripe of padding) a call may need
+constexpr uint32_t kStaticExtendBlocks = 256u;    // persistent traversal grid of the static variant (256-thread blocks)
+constexpr uint32_t kStaticSpill = ptr::kStackSpill;
+constexpr uint32_t kStaticMaxDepth = ptr::kStackLds + kStaticSpill - 3u;   // deepest layout the spill area covers
+constexpr size_t kStaticSpillWords = (size_t)kStaticExtendBlocks * (ptr::kExtendThreads / 64) * kStaticSpill * 64;
+constexpr size_t kStaticWords = (size_t)kStaticPaths * (2 * 12 + 8 + 1) + 64 + kStaticSpillWords;   // 34.2 MB
+static __device__ __align__(256) uint32_t scratch[kStaticWords];
+
+constexpr int kMaxDevices = 64;
+std::mutex g_static_mutex;
+uint32_t* g_static_scratch[kMaxDevices] = {};   // device address of `scratch` on each GPU that has a context
+
+// With `device` current: the address of this GPU's copy of the array.
+hipError_t static_scratch_address(int device, uint32_t** out) {
+    std::lock_guard<std::mutex> lock(g_static_mutex);
+    if (device < 0 || device >= kMaxDevices) return hipErrorInvalidDevice;
+    if (!g_static_scratch[device]) {
+        void* p = nullptr;
+        const hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+        if (e != hipSuccess) return e;
+        g_static_scratch[device] = (uint32_t*)p;
+    }
+    *out = g_static_scratch[device];
+    return hipSuccess;
+}
 
 int bind_device(ptr_ctx* c) {
     PTR_HIP_CHECK(c, hipSetDevice(c->device));
@@ -329,7 +361,7 @@ int check_storage_image(ptr_ctx* c, uint32_t index, const char* what) {
 // Per-triangle shading records of the wavefront shade step: (re)built when the index / positions / normals / uvs
 // addresses of the dispatch, or the contents of the buffers behind them, differ from what the records were built
 // from.  On success sv names the records; with the option off, or an empty index buffer, sv keeps the gather path.
-int ensure_shade_records(ptr_ctx* c, const uint64_t addr[7], const ptr_handle handles[7], ptr::SceneView* sv) {
+int ensure_shade_records(ptr_ctx* c, const uint64_t addr[7], const ptr_handle handles[7], ptr::SceneView* sv, bool lookup_only = false) {
     sv->shade_records = nullptr;
     sv->shade_record_count = 0;
     if (!c->opt_shade_pregather) return PTR_OK;
@@ -352,6 +384,7 @@ int ensure_shade_records(ptr_ctx* c, const uint64_t addr[7], const ptr_handle ha
         sv->shade_record_count = c->shade_record_count;
         return PTR_OK;
     }
+    if (lookup_only) return PTR_OK;   // no records for these buffers yet: the shade step gathers per hit (same results)
     const size_t need = (size_t)tris * ptr::kShadeRecordVec4 * sizeof(float4);
     c->shade_key_valid = false;
     { int rc = drain_frames(c); if (rc) return rc; }  // frames in flight read the records that are about to change
@@ -379,7 +412,7 @@ int ensure_shade_records(ptr_ctx* c, const uint64_t addr[7], const ptr_handle ha
 
 // The index words and the tree layouts hold indices into other buffers: checked on the GPU once per upload, so that a
 // bad scene fails the dispatch instead of faulting the device.
-int validate_scene(ptr_ctx* c, const uint64_t addr[7], const ptr_handle handles[7], const ptr::SceneView& sv, BufferRec* flat_buf, bool wavefront) {
+int validate_scene(ptr_ctx* c, const uint64_t addr[7], const ptr_handle handles[7], const ptr::SceneView& sv, BufferRec* flat_buf, bool wavefront, bool lookup_only = false) {
     if (!c->opt_validate) return PTR_OK;
     uint64_t key[16] = {};
     for (int i = 1; i < 7; i++) { key[i - 1] = addr[i]; key[5 + i] = c->buffers[handles[i]].generation; }
@@ -389,6 +422,9 @@ int validate_scene(ptr_ctx* c, const uint64_t addr[7], const ptr_handle handles[
     key[14] = top_buf ? top_buf->generation : 0;
     key[15] = top_buf ? (uint64_t)flat_buf->instances : 0;
     for (const auto& v : c->validated) if (v.used && !memcmp(v.key, key, sizeof key)) return PTR_OK;
+    if (lookup_only)
+        return fail(c, PTR_E_STATE, "ptr_dispatch_static: these scene buffers have not been checked since their last write; the check allocates, "
+                                    "so run one ptr_dispatch on them first (or set scene.validate to 0)");
 
     auto bytes_from = [&](int i) { const BufferRec& b = c->buffers[handles[i]]; return (uint64_t)(uintptr_t)b.ptr + b.size - addr[i]; };
     const uint64_t triangles = bytes_from(2) / (4u * (uint64_t)c->opt_index_words);
@@ -439,7 +475,9 @@ int validate_scene(ptr_ctx* c, const uint64_t addr[7], const ptr_handle handles[
     return PTR_OK;
 }
 
-int dispatch_compute(ptr_ctx* c, const uint8_t constants[64], uint32_t gx, uint32_t gy, int force /*0 auto,1 mega,2 wavefront*/) {
+// no_alloc: the ptr_dispatch_static variant -- the frame runs start to end on the context's stream in this GPU's fixed
+// scratch array, and nothing on the way allocates (no scene check, no record gathering, no streams or events).
+int dispatch_compute(ptr_ctx* c, const uint8_t constants[64], uint32_t gx, uint32_t gy, int force /*0 auto,1 mega,2 wavefront*/, bool no_alloc = false) {
     const ParsedConstants k = parse_constants(constants);
     ptr::SceneMeta meta;
     int rc = read_meta(c, k.addr[0], &meta);
@@ -503,7 +541,11 @@ int dispatch_compute(ptr_ctx* c, const uint8_t constants[64], uint32_t gx, uint3
     if (!wavefront) {
         // the threaded walk starts at node 0: at least one node must be there
         if (k.addr[1] + 32 > (uint64_t)(uintptr_t)bvh_buf->ptr + bvh_buf->size) return fail(c, PTR_E_STATE, "bvh buffer holds no node");
-        if ((rc = validate_scene(c, k.addr, handles, sv, nullptr, false))) return rc;
+        if ((rc = validate_scene(c, k.addr, handles, sv, nullptr, false, no_alloc))) return rc;
+        if (no_alloc) {   // no events either
+            PTR_HIP_CHECK(c, ptr::launch_megakernel(c->stream, sv, gx, gy, c->stats_on));
+            return PTR_OK;
+        }
         ScopedProfile prof(c, "compute.megakernel");
         PTR_HIP_CHECK(c, ptr::launch_megakernel(c->stream, sv, gx, gy, c->stats_on));
         return PTR_OK;
@@ -565,12 +607,43 @@ int dispatch_compute(ptr_ctx* c, const uint8_t constants[64], uint32_t gx, uint3
         sv.instance_count = fv.top.count;
         sv.object_triangles = flat_buf->flat_triangles;
     }
-    if ((rc = validate_scene(c, k.addr, handles, sv, flat_buf, true))) return rc;
-    if ((rc = ensure_shade_records(c, k.addr, handles, &sv))) return rc;
+    if ((rc = validate_scene(c, k.addr, handles, sv, flat_buf, true, no_alloc))) return rc;
+    if ((rc = ensure_shade_records(c, k.addr, handles, &sv, no_alloc))) return rc;
 
     const uint32_t domain_w = gx * 8u < meta.width ? gx * 8u : meta.width;
     const uint32_t domain_h = gy * 8u < meta.height ? gy * 8u : meta.height;
     if (domain_w == 0 || domain_h == 0) return PTR_OK;
+
+    // queue slots: whole 8x8 tiles of the owned rows (padded by one stripe); samples are indexed by pixel
+    const uint32_t padded = ((meta.width + 7u) / 8u) * ((meta.height + 7u) / 8u + c->part_stripe / 8u) * 64u;
+    const uint32_t paths = padded > meta.width * meta.height ? padded : meta.width * meta.height;
+
+    if (no_alloc) {
+        // one frame, start to end on the context's stream, in this GPU's fixed scratch array
+        if (paths > kStaticPaths)
+            return fail(c, PTR_E_RANGE, "ptr_dispatch_static: a %u x %u frame needs %u queue slots, the fixed scratch holds %u", meta.width, meta.height, paths, kStaticPaths);
+        if (fv.max_depth > kStaticMaxDepth)
+            return fail(c, PTR_E_RANGE, "ptr_dispatch_static: the layout needs a traversal stack of %u entries, the fixed scratch covers %u", fv.max_depth, kStaticMaxDepth);
+        ptr::WavefrontScratch w = c->static_scratch;
+        w.alone_turns = (uint32_t)c->opt_extend_alone_turns;
+        w.fault = c->fault_device;
+        hipStream_t ts = c->stream;
+        // the array keeps the last call's contents: the queue counters must start at zero
+        PTR_HIP_CHECK(c, hipMemsetAsync(w.counters, 0, 64 * sizeof(uint32_t), ts));
+        if (meta.max_bounce == 0) PTR_HIP_CHECK(c, hipMemsetAsync(w.samples, 0, (size_t)paths * 16, ts));
+        PTR_HIP_CHECK(c, ptr::launch_wf_generate(ts, sv, w, domain_w, domain_h));
+        for (uint32_t b = 0; b < meta.max_bounce; b++) {
+            if (b + 1 >= ptr::kMaxBounceSlots) {
+                const uint32_t s = (b + 1) % ptr::kMaxBounceSlots;
+                PTR_HIP_CHECK(c, hipMemsetAsync(w.counters + s, 0, 4, ts));
+                PTR_HIP_CHECK(c, hipMemsetAsync(w.counters + ptr::kMaxBounceSlots + s, 0, 4, ts));
+            }
+            PTR_HIP_CHECK(c, ptr::launch_wf_extend(ts, fv, w, b, sv.stats, c->opt_extend_refill, c->opt_extend_leaf_weight, c->opt_extend_leaf_all, c->opt_extend_inner_reps));
+            PTR_HIP_CHECK(c, ptr::launch_wf_shade(ts, sv, w, b, meta.max_bounce, meta.min_bounce, domain_w, domain_h));
+        }
+        PTR_HIP_CHECK(c, ptr::launch_wf_accumulate(ts, sv, w, domain_w, domain_h));
+        return PTR_OK;
+    }
 
     // Which stream traces this frame: one of the auxiliary frame slots, or (counting / capturing runs, or the option
     // set to 1) the context's own stream after everything in flight has finished.
@@ -581,9 +654,7 @@ int dispatch_compute(ptr_ctx* c, const uint8_t constants[64], uint32_t gx, uint3
     if (overlap && (rc = ensure_slot(c, slot))) return rc;
     hipStream_t ts = overlap ? slot.stream : c->stream;
 
-    // queue slots: whole 8x8 tiles of the owned rows (padded by one stripe); samples are indexed by pixel
-    const uint32_t padded = ((meta.width + 7u) / 8u) * ((meta.height + 7u) / 8u + c->part_stripe / 8u) * 64u;
-    if ((rc = ensure_scratch(c, slot, padded > meta.width * meta.height ? padded : meta.width * meta.height, fv.max_depth))) return rc;
+    if ((rc = ensure_scratch(c, slot, paths, fv.max_depth))) return rc;
     slot.scratch.alone_turns = (uint32_t)c->opt_extend_alone_turns;
     slot.scratch.fault = c->fault_device;
     const ptr::WavefrontScratch& w = slot.scratch;
@@ -659,6 +730,26 @@ int ptr_ctx_create(int device, ptr_ctx** out) {
     if ((e = hipHostMalloc((void**)&c->stage, (size_t)ptr_ctx::kStageSlots * kShadowLimit, hipHostMallocDefault)) != hipSuccess) return bail("hipHostMalloc(staging ring)", e);
     for (int i = 0; i < ptr_ctx::kStageSlots; i++)
         if ((e = hipEventCreateWithFlags(&c->stage_done[i], hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate(staging ring)", e);
+    {
+        // this GPU's copy of the fixed scratch array, carved up like an allocated frame scratch
+        uint32_t* p = nullptr;
+        if ((e = static_scratch_address(device, &p)) != hipSuccess) return bail("hipGetSymbolAddress(static scratch)", e);
+        auto take = [&](size_t n) { uint32_t* r = p; p += n; return r; };
+        ptr::WavefrontScratch& s = c->static_scratch;
+        s.hits = (float4*)take((size_t)kStaticPaths * 4);
+        s.samples = (float4*)take((size_t)kStaticPaths * 4);
+        for (int g = 0; g < 2; g++) {
+            s.ray_o[g] = (float4*)take((size_t)kStaticPaths * 4);
+            s.ray_d[g] = (float4*)take((size_t)kStaticPaths * 4);
+            s.path_t[g] = (float4*)take((size_t)kStaticPaths * 4);
+        }
+        s.hit_instance = (int32_t*)take(kStaticPaths);
+        s.counters = take(64);
+        s.stack_spill = (int32_t*)take(kStaticSpillWords);
+        s.capacity = kStaticPaths;
+        s.extend_blocks = kStaticExtendBlocks;
+        s.spill_entries = kStaticSpill;
+    }
     if ((e = hipHostMalloc((void**)&c->fault, 64, hipHostMallocMapped)) != hipSuccess) return bail("hipHostMalloc(fault word)", e);
     *c->fault = 0u;
     if ((e = hipHostGetDevicePointer((void**)&c->fault_device, (void*)c->fault, 0)) != hipSuccess) return bail("hipHostGetDevicePointer(fault word)", e);
@@ -1053,6 +1144,18 @@ int ptr_dispatch(ptr_ctx* c, const char* kernel, const uint8_t constants[64], ui
         return PTR_OK;
     }
     return fail(c, PTR_E_INVALID, "ptr_dispatch: unknown kernel '%s' (compute, compute.megakernel, compute.wavefront, tonemapping, linearize, resolve)", kernel);
+}
+
+int ptr_dispatch_static(ptr_ctx* c, const char* kernel, const uint8_t constants[64], uint32_t gx, uint32_t gy, uint32_t gz) {
+    if (!c) return PTR_E_INVALID;
+    if (!kernel || !constants) return fail(c, PTR_E_INVALID, "ptr_dispatch_static: null kernel name or constants");
+    int rc = bind_device(c); if (rc) return rc;
+    if (gx == 0 || gy == 0 || gz == 0) return PTR_OK;
+    if ((uint64_t)gx * gy > 0x7fffffffull) return fail(c, PTR_E_RANGE, "ptr_dispatch_static: too many workgroups");
+    if (!strcmp(kernel, "compute")) return dispatch_compute(c, constants, gx, gy, 0, true);
+    if (!strcmp(kernel, "compute.megakernel")) return dispatch_compute(c, constants, gx, gy, 1, true);
+    if (!strcmp(kernel, "compute.wavefront")) return dispatch_compute(c, constants, gx, gy, 2, true);
+    return fail(c, PTR_E_INVALID, "ptr_dispatch_static: unknown kernel '%s' (compute, compute.megakernel, compute.wavefront)", kernel);
 }
 
 int ptr_set_partition(ptr_ctx* c, uint32_t rank, uint32_t world, uint32_t stripe_rows) {

@@ -61,6 +61,7 @@ def lib():
         "ptr_bvh_bind_flat": [vp, u32, u32],
         "ptr_bvh_bind_instances": [vp, u32, u32],
         "ptr_dispatch": [vp, C.c_char_p, vp, u32, u32, u32],
+        "ptr_dispatch_static": [vp, C.c_char_p, vp, u32, u32, u32],
         "ptr_set_partition": [vp, u32, u32, u32],
         "ptr_set_sample_partition": [vp, u32, u32],
         "ptr_set_option": [vp, C.c_char_p, C.c_int],
@@ -87,7 +88,7 @@ def lib():
 ABI_SYMBOLS = ["ptr_ctx_create", "ptr_ctx_destroy", "ptr_ctx_set_stream", "ptr_last_error", "ptr_sync", "ptr_buffer_create",
                "ptr_buffer_destroy", "ptr_buffer_write", "ptr_buffer_read", "ptr_buffer_address", "ptr_sampler_create",
                "ptr_image_create", "ptr_image_wrap", "ptr_image_destroy", "ptr_image_upload", "ptr_image_read",
-               "ptr_image_index", "ptr_sampler_index", "ptr_image_address", "ptr_bvh_bind_flat", "ptr_bvh_bind_instances", "ptr_dispatch",
+               "ptr_image_index", "ptr_sampler_index", "ptr_image_address", "ptr_bvh_bind_flat", "ptr_bvh_bind_instances", "ptr_dispatch", "ptr_dispatch_static",
                "ptr_set_partition", "ptr_set_sample_partition", "ptr_set_option", "ptr_set_capture", "ptr_stats_enable", "ptr_stats_read", "ptr_profile_enable",
                "ptr_profile_read", "ptr_profile_names", "ptr_device_function", "ptr_bvh_build_flat", "ptr_bvh_flat_set_reference_ranks"]
 
@@ -207,6 +208,12 @@ class Context:
         k = np.ascontiguousarray(constants, dtype=np.uint8)
         assert k.nbytes == 64
         self._check(self._L.ptr_dispatch(self.handle, kernel.encode(), k.ctypes.data, gx, gy, gz))
+
+    def dispatch_static(self, kernel, constants, gx, gy, gz=1):
+        """ptr_dispatch_static: the same frame in the library's fixed per-GPU scratch array, nothing allocated."""
+        k = np.ascontiguousarray(constants, dtype=np.uint8)
+        assert k.nbytes == 64
+        self._check(self._L.ptr_dispatch_static(self.handle, kernel.encode(), k.ctypes.data, gx, gy, gz))
 
 
 class Buffer:

@@ -1,0 +1,72 @@
+"""ptr_dispatch_static -- the "compute" dispatch in the library's fixed per-GPU scratch array, for callers that cannot
+allocate -- against ptr_dispatch on the same inputs, through the C ABI.  Images are compared for equality (numpy `==`),
+like every other parity test of the path: both entry points run the same kernels on the same fp32 arithmetic."""
+import numpy as np
+import pytest
+
+from common import make_bundle, oracle_frames
+
+pytestmark = pytest.mark.gpu
+
+
+def render(ctx, gs, width, height, spp, static, pipeline="compute"):
+    """`spp` frames of the reference's frame protocol (src/main.cpp:406-416) through one of the two entry points."""
+    from path_tracer_amd import hip
+    loop = hip.FrameLoop(ctx, gs, width, height, pipeline)
+    if static:
+        loop.renderpass.execute = lambda: ctx.dispatch_static(pipeline, loop.renderpass.constants, *loop.renderpass.group_count)
+    for _ in range(spp):
+        loop.frame()
+    return loop.latest().read()
+
+
+def test_static_dispatch_equals_the_allocating_dispatch_twice_in_a_row_the_second_smaller():
+    from path_tracer_amd import hip
+    ctx = hip.Context(0)
+    try:
+        big = make_bundle("atrium", 6000, 200, 120, max_bounce=4)
+        small = make_bundle("tiny", 0, 56, 40, max_bounce=3)          # other scene, fewer pixels: shorter queues, stale tail behind them
+        gs_big = hip.GpuScene(ctx, big, big["nodes"], big["flat"], big["meta"])
+        gs_small = hip.GpuScene(ctx, small, small["nodes"], small["flat"], small["meta"])
+
+        # nothing has looked at these buffers yet, and looking allocates: the static entry point says so instead of guessing
+        with pytest.raises(hip.HipError, match="have not been checked"):
+            render(ctx, gs_big, 200, 120, 1, static=True)
+
+        want_big = render(ctx, gs_big, 200, 120, 3, static=False)     # also checks the scene and gathers the shading records
+        want_small = render(ctx, gs_small, 56, 40, 3, static=False)
+        ctx.sync()
+
+        got_big = render(ctx, gs_big, 200, 120, 3, static=True)       # first call ... (three frames each: the accumulation chain)
+        got_small = render(ctx, gs_small, 56, 40, 3, static=True)     # ... and a second, smaller one right behind it
+        assert np.array_equal(got_big, want_big), int((got_big != want_big).any(axis=-1).sum())
+        assert np.array_equal(got_small, want_small), int((got_small != want_small).any(axis=-1).sum())
+
+        # and both equal the oracle, so "equal to each other" is not two wrong pictures agreeing
+        ref, _, _ = oracle_frames(small, 3, use_flat=True, materials=gs_small.materials_host, textures=gs_small.texture_table)
+        assert np.array_equal(got_small, ref)
+
+        # the strict drop-in kernel needs no scratch at all; the static entry point launches it too
+        mega = render(ctx, gs_small, 56, 40, 2, static=False, pipeline="compute.megakernel")
+        assert np.array_equal(render(ctx, gs_small, 56, 40, 2, static=True, pipeline="compute.megakernel"), mega)
+
+        # back and forth between the two entry points on one context: neither disturbs the other
+        assert np.array_equal(render(ctx, gs_big, 200, 120, 2, static=False), render(ctx, gs_big, 200, 120, 2, static=True))
+    finally:
+        ctx.close()
+
+
+def test_static_dispatch_refuses_what_its_fixed_scratch_cannot_hold():
+    from path_tracer_amd import hip
+    ctx = hip.Context(0)
+    try:
+        b = make_bundle("tiny", 0, 640, 360, max_bounce=2)            # 230 400 pixels: more than 163 840 queue slots
+        gs = hip.GpuScene(ctx, b, b["nodes"], b["flat"], b["meta"])
+        render(ctx, gs, 640, 360, 1, static=False)
+        with pytest.raises(hip.HipError, match="queue slots"):
+            render(ctx, gs, 640, 360, 1, static=True)
+        small = dict(b, meta=make_bundle("tiny", 0, 64, 40, max_bounce=2)["meta"], width=64, height=40)
+        gs.set_meta(small["meta"])                                     # the same scene at a size that fits goes through
+        assert np.array_equal(render(ctx, gs, 64, 40, 2, static=True), render(ctx, gs, 64, 40, 2, static=False))
+    finally:
+        ctx.close()
