@@ -40,13 +40,19 @@ def _padded_view(image, stripe_rows, world):
 def gather_tiles(image, rank, world, stripe_rows, group=None):
     """All-gathers the stripes each rank owns into the full frame.  `image` is this rank's (H, W, 4) frame whose
     owned rows are valid; returns the merged (H, W, 4) frame (a new tensor), identical on every rank."""
-    if world == 1:
+    if world == 1 and not dist.is_initialized():
         return image.clone()
     H = image.shape[0]
     stripes, n_padded = _padded_view(image, stripe_rows, world)
     mine = stripes[rank::world].contiguous()                      # (n_padded / world, stripe_rows, W, 4)
-    gathered = torch.empty((world,) + tuple(mine.shape), dtype=image.dtype, device=image.device)
-    dist.all_gather_into_tensor(gathered.view(-1), mine.view(-1), group=group)
+    if image.is_cuda and dist.get_backend(group) == "gloo":
+        # rehearsal path (gloo has no device collectives here): stage through host memory
+        parts = [torch.empty(mine.shape, dtype=image.dtype) for _ in range(world)]
+        dist.all_gather(parts, mine.cpu(), group=group)
+        gathered = torch.stack(parts).to(image.device)
+    else:
+        gathered = torch.empty((world,) + tuple(mine.shape), dtype=image.dtype, device=image.device)
+        dist.all_gather_into_tensor(gathered.view(-1), mine.view(-1), group=group)
     # gathered[r, j] is stripe j * world + r
     merged = gathered.permute(1, 0, 2, 3, 4).reshape(n_padded * stripe_rows, image.shape[1], image.shape[2])
     return merged[:H].contiguous()

@@ -4,6 +4,8 @@ that traces ~0.5 Mrays/s allow:
       traversal order on every pixel (ties counted, not hidden), and the image bit for bit;
   C3  street interior 1920x1080, max_bounce 4, several samples: the oracle on sampled row bands, bit for bit
       (stronger than the RMSE bound the contract asks for);
+  headline  the benchmark's own scene at the benchmark's own size, against the oracle on row bands, bit for bit;
+  C1  atrium 1280x720, max_bounce 4: both pipelines against the oracle on row bands;
   C4  street exterior 3840x2160 in tile mode over 4 ranks: the union of the ranks' stripes is bit-identical to the
       single-GPU frame (the ranks are four partitions of one context here; the all-gather is tested on CPU)."""
 import numpy as np
@@ -20,6 +22,66 @@ def ctx():
     c = hip.Context(0)
     yield c
     c.close()
+
+
+def oracle_bands(bundle, gs, bands, spp, use_flat=True):
+    """The oracle on a few row bands of a frame too large to render whole on the CPU: `spp` samples, each band's accumulation
+    chain kept (sample s needs the rows sample s-1 left behind)."""
+    import pyoracle
+    o = pyoracle.OracleScene(dict(bundle, materials=gs.materials_host, textures=gs.texture_table))
+    H, W = bundle["height"], bundle["width"]
+    acc = np.zeros((H, W, 4), np.float32)
+    out = np.zeros_like(acc)
+    for s in range(1, spp + 1):
+        o.set_meta(sample_index=s)
+        for r in bands:
+            o.render(acc, out, rows=r, use_flat=use_flat, threads=16)
+        acc, out = out, acc
+    return acc
+
+
+def assert_bands_equal(img, ref, bands, what):
+    for y0, y1 in bands:
+        bad = int((img[y0:y1] != ref[y0:y1]).any(axis=-1).sum())
+        assert bad == 0, f"{what}: {bad} pixels of rows {y0}:{y1} differ from the oracle"
+
+
+def test_headline_workload_street_exterior_2_8m_triangles_1080p(ctx):
+    """The exact workload bench.py times (its own scene builder with its default arguments: 2 796 540 triangles, 512^2
+    textures, 1920x1080, max_bounce 4, "compute" with two frames in flight), three samples, against the oracle on six row
+    bands spread over the frame -- bit for bit."""
+    import os
+    import sys
+    from path_tracer_amd import hip
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    args = bench.make_parser().parse_args([])
+    sc, nodes, flat, meta, _ = bench.build_scene(args, rank=1)
+    assert sc["triangles"].shape[0] == 2_796_540 and (args.width, args.height, args.bounces) == (1920, 1080, 4)
+    b = dict(sc, nodes=nodes, flat=flat, meta=meta, width=args.width, height=args.height)
+    gs = hip.GpuScene(ctx, b, nodes, flat, meta)
+    spp = 3
+    img, _, _, st = gpu_frames(ctx, b, spp, args.pipeline, gpu_scene=gs)
+    bands = [(0, 8), (200, 208), (416, 424), (640, 648), (856, 864), (1072, 1080)]
+    assert_bands_equal(img, oracle_bands(b, gs, bands, spp), bands, "headline workload")
+    assert np.isfinite(img).all() and (img[..., 3] == 1.0).all()
+    # the counting variant sees the same work the benchmark line reports: about 5.15 M rays per frame
+    _, _, _, st = gpu_frames(ctx, b, 1, args.pipeline, gpu_scene=gs, stats=True)
+    assert 5.0e6 < st["rays"] < 5.3e6, st
+
+
+def test_c1_atrium_720p_four_bounces(ctx):
+    """C1's workload (Sponza-class atrium, 262 k triangles, 1280x720, 1 spp, max_bounce 4) on the HIP path: the strict drop-in
+    kernel against the oracle's walk of the reference's own tree, the fast path against the oracle's walk of the flattened
+    layout, both on row bands, bit for bit."""
+    b = make_bundle("atrium", 262144, 1280, 720, max_bounce=4)
+    assert 250_000 < b["triangles"].shape[0] < 275_000
+    bands = [(0, 4), (180, 184), (356, 364), (540, 544), (716, 720)]
+    img, gs, _, _ = gpu_frames(ctx, b, 1, "compute")
+    assert_bands_equal(img, oracle_bands(b, gs, bands, 1, use_flat=True), bands, "C1 wavefront")
+    mega, _, _, _ = gpu_frames(ctx, b, 1, "compute.megakernel", gpu_scene=gs)
+    thin = [(0, 2), (358, 360), (718, 720)]                        # the reference-order tree costs ~670 nodes per ray on the CPU
+    assert_bands_equal(mega, oracle_bands(b, gs, thin, 1, use_flat=False), thin, "C1 megakernel")
 
 
 def test_c2_atrium_1080p_first_two_hits_and_image(ctx):
@@ -41,22 +103,12 @@ def test_c2_atrium_1080p_first_two_hits_and_image(ctx):
 
 
 def test_c3_street_interior_1080p_sampled_bands(ctx):
-    import pyoracle
-    spp = 3
+    spp = 16                                                       # the sample count the configuration states
     b = make_bundle("street_interior", 1_000_000, 1920, 1080, max_bounce=4)
     assert 950_000 < b["triangles"].shape[0] < 1_050_000
     img, gs, _, _ = gpu_frames(ctx, b, spp, "compute.wavefront")
-    o = pyoracle.OracleScene(dict(b, materials=gs.materials_host, textures=gs.texture_table))
-    acc = np.zeros((1080, 1920, 4), np.float32)
-    out = np.zeros_like(acc)
     bands = [(0, 4), (268, 272), (540, 544), (812, 816), (1076, 1080)]
-    for s in range(1, spp + 1):
-        o.set_meta(sample_index=s)
-        for r in bands:
-            o.render(acc, out, rows=r, use_flat=True, threads=16)
-        acc, out = out, acc
-    for y0, y1 in bands:
-        assert np.array_equal(img[y0:y1], acc[y0:y1]), f"rows {y0}:{y1}"
+    assert_bands_equal(img, oracle_bands(b, gs, bands, spp), bands, "C3, 16 samples")
     assert np.isfinite(img).all() and img[..., :3].min() >= 0.0 and img[..., :3].max() <= 1.0 and (img[..., 3] == 1.0).all()
 
 
@@ -76,6 +128,47 @@ def test_c4_street_exterior_4k_tile_mode(ctx):
     finally:
         ctx.set_partition(0, 1, 8)
     assert np.array_equal(merged, whole)
+
+
+def test_c5_100m_triangles_as_36_placed_copies_one_rank_of_eight(ctx):
+    """C5 at its size: the benchmark's scene placed 6 x 6 times through a top-level tree (100.7 M triangles), 1920x1080,
+    max_bounce 4, the samples dealt to 8 ranks.  This GPU plays rank 5: its frames -- global samples 6 and 14 -- against the
+    oracle's two-level traversal seeded with the same sample numbers, on row bands, bit for bit.  (What the ranks then do with
+    their images -- linearise, all-reduce, resolve -- is pinned at small size in the parity tests and on CPU ranks.)"""
+    import os
+    import sys
+    import pyoracle
+    from path_tracer_amd import hip
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    args = bench.make_parser().parse_args(["--instances", "6x6", "--two-level"])
+    sc, nodes, flat, meta, _ = bench.build_scene(args, rank=1)
+    assert sc["triangles"].shape[0] * 36 == 100_675_440 and sc["flat_instances"] is not None
+    b = dict(sc, nodes=nodes, flat=flat, meta=meta, width=args.width, height=args.height)
+    gs = hip.GpuScene(ctx, b, nodes, flat, meta)
+    world, rank, frames = 8, 5, 2
+    H, W = args.height, args.width
+    try:
+        ctx.set_sample_partition(rank, world)
+        img, _, _, _ = gpu_frames(ctx, b, frames, "compute", gpu_scene=gs)
+    finally:
+        ctx.set_sample_partition(0, 1)
+    o = pyoracle.OracleScene(dict(b, materials=gs.materials_host, textures=gs.texture_table))
+    acc = np.zeros((H, W, 4), np.float32)
+    out = np.zeros_like(acc)
+    bands = [(0, 4), (300, 304), (538, 542), (800, 804), (1076, 1080)]
+    hit_copies = set()
+    for k in range(1, frames + 1):
+        o.set_meta(sample_index=k)
+        o.seed_sample_index = (k - 1) * world + rank + 1
+        for r in bands:
+            cap = (np.full((H, W, 2), -1, np.int32), np.zeros((H, W, 2), np.float32))
+            o.render(acc, out, rows=r, use_flat=True, threads=16, aov=cap)
+            ids = cap[0][r[0]:r[1], :, 0]
+            hit_copies |= set(np.unique(ids[ids >= 0] // sc["triangles"].shape[0]).tolist())
+        acc, out = out, acc
+    assert len(hit_copies) >= 6, hit_copies                          # the bands see many of the copies
+    assert_bands_equal(img, acc, bands, "C5, rank 5 of 8")
 
 
 def test_c5_placed_copies_sample_partition_vs_sequential(ctx):
