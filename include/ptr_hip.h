@@ -132,6 +132,13 @@ int ptr_dispatch_static(ptr_ctx* ctx, const char* kernel, const uint8_t constant
  *      the 8-row-aligned stripes s with s % world == rank, stripe = stripe_rows image rows.
  *      world = 1 restores the whole frame. ---- */
 int ptr_set_partition(ptr_ctx* ctx, uint32_t rank, uint32_t world, uint32_t stripe_rows);
+/* The exchange of the tile partition (no counterpart in the reference): an all-gather moves one contiguous chunk per rank.
+ * pack: the stripes `rank` owns of an RGBA32_SFLOAT image, in order, into `packed` -- ceil(stripes / world) stripes of
+ * stripe_rows * width * 16 bytes, rows past the image's end zero.  unpack: `world` such chunks in rank order (what the
+ * all-gather delivers), chunk r's stripe j being stripe j * world + r of the frame, back into the image's rows.
+ * Stream-ordered on the context's stream like a dispatch. */
+int ptr_image_pack_stripes(ptr_ctx* ctx, ptr_handle image, uint32_t rank, uint32_t world, uint32_t stripe_rows, ptr_handle packed);
+int ptr_image_unpack_stripes(ptr_ctx* ctx, ptr_handle image, uint32_t world, uint32_t stripe_rows, ptr_handle gathered);
 /* ---- multi-GPU sample partition (no counterpart in the reference): frame `sample_index` of this context
  *      draws the global sample (sample_index - 1) * world + rank + 1 over the whole frame and keeps the running
  *      mean of its own samples.  The per-GPU means are combined with the two extra dispatch names

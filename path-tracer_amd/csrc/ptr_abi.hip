@@ -1166,6 +1166,31 @@ int ptr_set_partition(ptr_ctx* c, uint32_t rank, uint32_t world, uint32_t stripe
     return PTR_OK;
 }
 
+static int stripes_copy(ptr_ctx* c, const char* who, ptr_handle image, uint32_t rank, uint32_t ranks, uint32_t world, uint32_t stripe_rows, ptr_handle buffer, bool unpack) {
+    if (!c) return PTR_E_INVALID;
+    ImageRec* im = find_image(c, image);
+    BufferRec* b = find_buffer(c, buffer);
+    if (!im || !b) return fail(c, PTR_E_INVALID, "%s: unknown image or buffer", who);
+    if (im->format != PTR_FORMAT_RGBA32_SFLOAT) return fail(c, PTR_E_UNSUPPORTED, "%s: the image must be RGBA32_SFLOAT", who);
+    if (world == 0 || rank >= world || stripe_rows == 0 || (stripe_rows & 7u) || stripe_rows > 65536u) return fail(c, PTR_E_INVALID, "%s: rank %u / world %u / stripe_rows %u", who, rank, world, stripe_rows);
+    const uint64_t stripes = ((uint64_t)im->h + stripe_rows - 1u) / stripe_rows;
+    const uint64_t chunk_bytes = ((stripes + world - 1u) / world) * stripe_rows * im->w * 16u;
+    if (chunk_bytes * ranks > b->size) return fail(c, PTR_E_RANGE, "%s: the buffer holds %zu bytes, %llu needed", who, b->size, (unsigned long long)(chunk_bytes * ranks));
+    if (chunk_bytes * ranks / 16u > 0xffffffffull * 256ull) return fail(c, PTR_E_RANGE, "%s: frame too large", who);
+    int rc = bind_device(c); if (rc) return rc;
+    PTR_HIP_CHECK(c, ptr::launch_stripes_copy(c->stream, (float4*)im->ptr, im->w, im->h, stripe_rows, world, rank, ranks, (float4*)b->ptr, unpack));
+    if (!unpack) b->generation = ++c->write_epoch;
+    return PTR_OK;
+}
+
+int ptr_image_pack_stripes(ptr_ctx* c, ptr_handle image, uint32_t rank, uint32_t world, uint32_t stripe_rows, ptr_handle packed) {
+    return stripes_copy(c, "ptr_image_pack_stripes", image, rank, 1u, world, stripe_rows, packed, false);
+}
+
+int ptr_image_unpack_stripes(ptr_ctx* c, ptr_handle image, uint32_t world, uint32_t stripe_rows, ptr_handle gathered) {
+    return stripes_copy(c, "ptr_image_unpack_stripes", image, 0u, world, world, stripe_rows, gathered, true);
+}
+
 int ptr_set_sample_partition(ptr_ctx* c, uint32_t rank, uint32_t world) {
     if (!c) return PTR_E_INVALID;
     if (world == 0 || rank >= world) return fail(c, PTR_E_INVALID, "ptr_set_sample_partition: rank %u / world %u", rank, world);

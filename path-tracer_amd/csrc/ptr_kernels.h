@@ -64,6 +64,11 @@ hipError_t launch_tonemap(hipStream_t s, const SceneMeta* meta, const ImageDesc*
 hipError_t launch_linearize_resolve(hipStream_t s, const ImageDesc* images, uint32_t output_index, uint32_t accumulation_index,
                                     uint32_t pixels, bool resolve);
 
+// Tile-partition exchange: copies between the rows of an RGBA32F frame and the packed chunks an all-gather moves.
+// pack (unpack = false): ranks = 1, first_rank = the owner; unpack: first_rank = 0, ranks = world.
+hipError_t launch_stripes_copy(hipStream_t s, float4* image, uint32_t width, uint32_t height, uint32_t stripe_rows, uint32_t world,
+                               uint32_t first_rank, uint32_t ranks, float4* packed, bool unpack);
+
 // Wavefront stages.  domain_w/h = pixels of the dispatch that exist (min(groups*8, width/height)).
 hipError_t launch_wf_generate(hipStream_t s, const SceneView& sv, const WavefrontScratch& w, uint32_t domain_w, uint32_t domain_h);
 hipError_t launch_wf_extend(hipStream_t s, const FlatView& fv, const WavefrontScratch& w, uint32_t bounce, unsigned long long* stats,

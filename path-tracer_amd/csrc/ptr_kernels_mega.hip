@@ -148,6 +148,36 @@ hipError_t launch_linearize_resolve(hipStream_t s, const ImageDesc* images, uint
     return hipGetLastError();
 }
 
+// Tile-partition exchange helpers (no counterpart in the single-GPU reference).  A frame of `height` rows is cut into
+// stripes of `stripe_rows` rows; rank r of `world` owns the stripes s with s % world == r.  pack: the owned stripes of one
+// rank, in order, as one contiguous chunk (`chunk_stripes` stripes, rows past the frame's end zero) -- what an all-gather
+// sends.  unpack: `world` such chunks, [r][j] = stripe j * world + r, back into the rows of the frame.
+__global__ __launch_bounds__(256) void ptr_stripes_copy(float4* image, uint32_t width, uint32_t height, uint32_t stripe_rows, uint32_t world,
+                                                       uint32_t first_rank, uint32_t ranks, uint32_t chunk_stripes, float4* packed, uint32_t unpack) {
+    const uint64_t per_stripe = (uint64_t)stripe_rows * width;
+    const uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;          // texel of the packed side
+    if (i >= (uint64_t)ranks * chunk_stripes * per_stripe) return;
+    const uint32_t r = first_rank + (uint32_t)(i / (chunk_stripes * per_stripe));
+    const uint64_t in_chunk = i % (chunk_stripes * per_stripe);
+    const uint32_t j = (uint32_t)(in_chunk / per_stripe);
+    const uint64_t in_stripe = in_chunk % per_stripe;
+    const uint64_t row = (uint64_t)(j * world + r) * stripe_rows + in_stripe / width;
+    const bool inside = row < height;
+    if (unpack) { if (inside) image[row * width + in_stripe % width] = packed[i]; }
+    else packed[i] = inside ? image[row * width + in_stripe % width] : make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+hipError_t launch_stripes_copy(hipStream_t s, float4* image, uint32_t width, uint32_t height, uint32_t stripe_rows, uint32_t world,
+                               uint32_t first_rank, uint32_t ranks, float4* packed, bool unpack) {
+    const uint32_t stripes = (height + stripe_rows - 1u) / stripe_rows;
+    const uint32_t chunk_stripes = (stripes + world - 1u) / world;
+    const uint64_t texels = (uint64_t)ranks * chunk_stripes * stripe_rows * width;
+    if (texels == 0) return hipSuccess;
+    hipLaunchKernelGGL(ptr_stripes_copy, dim3((uint32_t)((texels + 255u) / 256u)), dim3(256), 0, s, image, width, height, stripe_rows, world,
+                       first_rank, ranks, chunk_stripes, packed, unpack ? 1u : 0u);
+    return hipGetLastError();
+}
+
 hipError_t launch_megakernel(hipStream_t s, const SceneView& sv, uint32_t groups_x, uint32_t groups_y, bool stats) {
     const uint32_t blocks = groups_x * groups_y;
     if (blocks == 0) return hipSuccess;

@@ -5,6 +5,16 @@
 //   ptr_headless --scene file.{ptrscene,gltf,glb} [--apply-transforms | --instanced] [--gpu-bvh] [--copies NX NZ] --width W --height H --spp N [--max-bounce B] [--min-bounce B]
 //                [--dof 0|1] [--downscale D] [--debug-bvh 0|1] [--pipeline compute|compute.megakernel|compute.wavefront]
 //                [--pos x y z] [--target x y z] [--fov deg] [--aperture a] [--focus f] [--out image.pfm|image.ppm|image.png]
+//                [--gpus N [--partition tiles|samples] [--transport rccl|file] [--stripe-rows S] [--rendezvous DIR]]
+//
+// --gpus N (no counterpart in the single-device reference): the process starts N copies of itself, one per GPU, each with
+// --rank r; the scene is replicated.  tiles: every rank renders the stripes s % N == r of all `spp` frames, one all-gather
+// merges the frame (bit-identical to one GPU).  samples: every rank renders spp / N whole frames of its own samples, one
+// all-reduce of the linearised images combines them.  Rank 0 writes the image.  --transport file stages the exchange through
+// files (several ranks on one GPU, for rehearsal); rccl uses the GPUs' xGMI links.
+#include <sys/wait.h>
+#include <unistd.h>
+
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -14,6 +24,7 @@
 #include <vector>
 
 #include "compute-renderpass.hpp"
+#include "exchange.hpp"
 #include "gltf.hpp"
 #include "hip-renderer.hpp"
 #include "image.hpp"
@@ -53,12 +64,47 @@ scene_source load_source(const std::string& path, bool apply_transforms, bool in
     if (ext == ".gltf" || ext == ".glb") return gltf(path).flatten(apply_transforms);
     return scene_source::load(path);
 }
+// --gpus N without --rank: one child process per GPU (started before this process touches a GPU), the worst exit code wins.
+int launch_ranks(int argc, char** argv, uint32_t gpus, std::string rendezvous) {
+    if (rendezvous.empty()) {
+        char tmpl[] = "/tmp/ptr_headless_XXXXXX";
+        if (!mkdtemp(tmpl)) { std::perror("mkdtemp"); return 2; }
+        rendezvous = tmpl;
+    }
+    std::vector<pid_t> children;
+    for (uint32_t r = 0; r < gpus; r++) {
+        const pid_t pid = fork();
+        if (pid < 0) { std::perror("fork"); return 2; }
+        if (pid == 0) {
+            std::vector<std::string> args(argv, argv + argc);
+            args.push_back("--rank"); args.push_back(std::to_string(r));
+            args.push_back("--rendezvous"); args.push_back(rendezvous);
+            std::vector<char*> raw;
+            for (auto& a : args) raw.push_back(&a[0]);
+            raw.push_back(nullptr);
+            execv("/proc/self/exe", raw.data());
+            std::perror("execv");
+            _exit(127);
+        }
+        children.push_back(pid);
+    }
+    int worst = 0;
+    for (pid_t pid : children) {
+        int status = 0;
+        if (waitpid(pid, &status, 0) < 0 || !WIFEXITED(status) || WEXITSTATUS(status) != 0) worst = WIFEXITED(status) && WEXITSTATUS(status) ? WEXITSTATUS(status) : 1;
+    }
+    return worst;
+}
 }  // namespace
 
 int main(int argc, char** argv) {
     std::string scene_path, out_path, pipeline = "compute";
     bool apply_transforms = false, gpu_bvh = false, instanced = false;
     uint32_t copies_x = 1, copies_z = 1;
+    uint32_t gpus = 1, stripe_rows = 8;
+    int rank = -1, device = -1;
+    bool transport_given = false;   // with --gpus 1: run the exchange anyway, alone (rehearses the RCCL calls on a one-GPU box)
+    std::string partition = "tiles", transport = "rccl", rendezvous;
     uint32_t width = 400, height = 225, spp = 1, max_bounce = 3, min_bounce = 1, dof = 0, debug_bvh = 0;
     int32_t downscale = 1;
     float pos[3] = { 13.f, 2.f, -3.f }, target[3] = { 0.f, 0.f, 0.f }, v_fov = 90.f, aperture = 0.1f, focus = 10.f;  // src/main.cpp:219-223
@@ -70,6 +116,13 @@ int main(int argc, char** argv) {
         else if (is("--gpu-bvh")) gpu_bvh = true;
         else if (is("--instanced")) instanced = true;
         else if (is("--copies")) { copies_x = (uint32_t)std::atoi(next()); copies_z = (uint32_t)std::atoi(next()); }
+        else if (is("--gpus")) gpus = (uint32_t)std::atoi(next());
+        else if (is("--rank")) rank = std::atoi(next());
+        else if (is("--device")) device = std::atoi(next());
+        else if (is("--partition")) partition = next();
+        else if (is("--transport")) { transport = next(); transport_given = true; }
+        else if (is("--rendezvous")) rendezvous = next();
+        else if (is("--stripe-rows")) stripe_rows = (uint32_t)std::atoi(next());
         else if (is("--out")) out_path = next();
         else if (is("--pipeline")) pipeline = next();
         else if (is("--width")) width = (uint32_t)std::atoi(next());
@@ -89,8 +142,24 @@ int main(int argc, char** argv) {
     }
     if (scene_path.empty()) { std::fprintf(stderr, "usage: ptr_headless --scene file.{ptrscene,gltf,glb} [options]\n"); return 2; }
 
+    if (gpus == 0 || (partition != "tiles" && partition != "samples")) { std::fprintf(stderr, "--gpus N >= 1, --partition tiles|samples\n"); return 2; }
+    if (gpus > 1 && rank < 0) return launch_ranks(argc, argv, gpus, rendezvous);
+    if (gpus > 1 && (uint32_t)rank >= gpus) { std::fprintf(stderr, "--rank %d of %u\n", rank, gpus); return 2; }
+    if (gpus == 1) rank = 0;
+    const bool tiles = partition == "tiles";
+    if (gpus > 1 && !tiles && spp % gpus != 0) { std::fprintf(stderr, "--partition samples: --spp must be a multiple of --gpus\n"); return 2; }
+    if (device < 0) device = (gpus > 1 && transport == "rccl") ? rank : 0;
+
     try {
-        hiprenderer renderer(0);
+        hiprenderer renderer(device);
+        std::unique_ptr<device_exchange> exchange;
+        if (gpus > 1 || transport_given) {
+            if (rendezvous.empty()) { char tmpl[] = "/tmp/ptr_headless_XXXXXX"; if (!mkdtemp(tmpl)) throw std::runtime_error("mkdtemp failed"); rendezvous = tmpl; }
+            exchange = device_exchange::create(transport, (uint32_t)rank, gpus, rendezvous, device);
+            if (tiles) hiprenderer::check(ptr_set_partition(hiprenderer::api, (uint32_t)rank, gpus, stripe_rows), "ptr_set_partition");
+            else hiprenderer::check(ptr_set_sample_partition(hiprenderer::api, (uint32_t)rank, gpus), "ptr_set_sample_partition");
+        }
+        const uint32_t frames = (gpus > 1 && !tiles) ? spp / gpus : spp;
         const float aspect_ratio = (float)width / (float)height;
         const auto t_build = std::chrono::steady_clock::now();
         scene main_scene(camera(point3{ pos[0], pos[1], pos[2] }, point3{ target[0], target[1], target[2] }, v_fov, aspect_ratio, aperture, focus), width, height,
@@ -114,7 +183,7 @@ int main(int argc, char** argv) {
         raytracing_pass->set_dispatch_size(width / 8 + 1, height / 8 + 1, 1);
 
         const auto t0 = std::chrono::steady_clock::now();
-        for (uint32_t frame = 0; frame < spp; frame++) {
+        for (uint32_t frame = 0; frame < frames; frame++) {
             raytracing_pass->set_ouput_texture(output_texture);
             raytracing_pass->set_constant(60, accumulation_texture);
             renderer.begin_frame();
@@ -124,12 +193,36 @@ int main(int argc, char** argv) {
             std::swap(output_texture, accumulation_texture);
             renderer.finish_frame();
         }
+        if (exchange && tiles) {
+            // one all-gather of the owned stripes; after the swap the last written image is `accumulation_texture`
+            const size_t chunk_bytes = stripe_chunk_texels(width, height, stripe_rows, gpus) * 16;
+            Buffer packed(chunk_bytes), gathered(chunk_bytes * gpus);
+            hiprenderer::check(ptr_image_pack_stripes(hiprenderer::api, accumulation_texture->device_image, (uint32_t)rank, gpus, stripe_rows, packed.device_buffer), "ptr_image_pack_stripes");
+            renderer.wait_idle();
+            exchange->all_gather(packed.device_address(), gathered.device_address(), chunk_bytes);
+            hiprenderer::check(ptr_image_unpack_stripes(hiprenderer::api, accumulation_texture->device_image, gpus, stripe_rows, gathered.device_buffer), "ptr_image_unpack_stripes");
+        } else if (exchange) {
+            // linearise this GPU's running mean, sum over the GPUs, resolve (alpha carries the number of contributions)
+            uint8_t block[64] = {};
+            auto run = [&](const char* kernel, Texture* out, Texture* in) {
+                const uint32_t o = out->bindless_index(), a = in->bindless_index();
+                std::memcpy(block + 56, &o, 4); std::memcpy(block + 60, &a, 4);
+                hiprenderer::check(ptr_dispatch(hiprenderer::api, kernel, block, 1, 1, 1), kernel);
+            };
+            run("linearize", output_texture, accumulation_texture);
+            renderer.wait_idle();
+            uint64_t address = 0;
+            hiprenderer::check(ptr_image_address(hiprenderer::api, output_texture->device_image, &address), "ptr_image_address");
+            exchange->all_reduce_sum(address, (size_t)width * height * 4);
+            run("resolve", accumulation_texture, output_texture);
+        }
         renderer.wait_idle();
         const double render_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-        std::fprintf(stderr, "ptr_headless: %zu triangles x %zu (%s BVH), scene build %.2f s, %u frames %ux%u in %.3f s (%.3f ms/frame)\n",
-                     main_scene.triangle_count, main_scene.copy_count, main_scene.bvh_mode.c_str(), build_s, spp, width, height, render_s, render_s * 1e3 / (spp ? spp : 1));
+        std::fprintf(stderr, "ptr_headless%s: %zu triangles x %zu (%s BVH), scene build %.2f s, %u frames %ux%u in %.3f s (%.3f ms/frame)\n",
+                     exchange ? (" [rank " + std::to_string(rank) + " of " + std::to_string(gpus) + ", " + partition + " over " + exchange->transport() + "]").c_str() : "",
+                     main_scene.triangle_count, main_scene.copy_count, main_scene.bvh_mode.c_str(), build_s, frames, width, height, render_s, render_s * 1e3 / (frames ? frames : 1));
 
-        if (!out_path.empty()) {
+        if (!out_path.empty() && rank == 0) {
             std::vector<float> rgba((size_t)width * height * 4);
             accumulation_texture->read(rgba.data());  // after the swap the last written image is `accumulation_texture`
             write_image(out_path, rgba, width, height);

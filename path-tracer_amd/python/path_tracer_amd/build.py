@@ -21,7 +21,7 @@ def build_hip(jobs=4):
 
 def build_headless():
     """The C++ headless driver (links libptr_hip.so through its C ABI)."""
-    _make(paths.HOST, "ptr_headless")
+    _make(paths.HOST, "ptr_headless", "exchange_selftest")
     return os.path.join(paths.HOST, "ptr_headless")
 
 

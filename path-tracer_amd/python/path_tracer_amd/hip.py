@@ -63,6 +63,8 @@ def lib():
         "ptr_dispatch": [vp, C.c_char_p, vp, u32, u32, u32],
         "ptr_dispatch_static": [vp, C.c_char_p, vp, u32, u32, u32],
         "ptr_set_partition": [vp, u32, u32, u32],
+        "ptr_image_pack_stripes": [vp, u32, u32, u32, u32, u32],
+        "ptr_image_unpack_stripes": [vp, u32, u32, u32, u32],
         "ptr_set_sample_partition": [vp, u32, u32],
         "ptr_set_option": [vp, C.c_char_p, C.c_int],
         "ptr_set_capture": [vp, u32],
@@ -89,7 +91,7 @@ ABI_SYMBOLS = ["ptr_ctx_create", "ptr_ctx_destroy", "ptr_ctx_set_stream", "ptr_l
                "ptr_buffer_destroy", "ptr_buffer_write", "ptr_buffer_read", "ptr_buffer_address", "ptr_sampler_create",
                "ptr_image_create", "ptr_image_wrap", "ptr_image_destroy", "ptr_image_upload", "ptr_image_read",
                "ptr_image_index", "ptr_sampler_index", "ptr_image_address", "ptr_bvh_bind_flat", "ptr_bvh_bind_instances", "ptr_dispatch", "ptr_dispatch_static",
-               "ptr_set_partition", "ptr_set_sample_partition", "ptr_set_option", "ptr_set_capture", "ptr_stats_enable", "ptr_stats_read", "ptr_profile_enable",
+               "ptr_set_partition", "ptr_image_pack_stripes", "ptr_image_unpack_stripes", "ptr_set_sample_partition", "ptr_set_option", "ptr_set_capture", "ptr_stats_enable", "ptr_stats_read", "ptr_profile_enable",
                "ptr_profile_read", "ptr_profile_names", "ptr_device_function", "ptr_bvh_build_flat", "ptr_bvh_flat_set_reference_ranks"]
 
 
@@ -145,6 +147,12 @@ class Context:
     # ---- instrumentation ----
     def set_partition(self, rank, world, stripe_rows=8):
         self._check(self._L.ptr_set_partition(self.handle, rank, world, stripe_rows))
+
+    def pack_stripes(self, image, rank, world, stripe_rows, packed_buffer):
+        self._check(self._L.ptr_image_pack_stripes(self.handle, image.handle, rank, world, stripe_rows, packed_buffer.handle))
+
+    def unpack_stripes(self, image, world, stripe_rows, gathered_buffer):
+        self._check(self._L.ptr_image_unpack_stripes(self.handle, image.handle, world, stripe_rows, gathered_buffer.handle))
 
     def set_sample_partition(self, rank, world):
         self._check(self._L.ptr_set_sample_partition(self.handle, rank, world))

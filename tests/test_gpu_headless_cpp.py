@@ -128,6 +128,71 @@ def test_headless_driver_debug_bvh_heatmap(tmp_path):
     assert img[..., 0].max() > 0 and img[..., 1].max() == 0
 
 
+def headless_cmd(b, scene_file, out_file, W, H, spp, *extra):
+    c = b["camera"]
+    return [HEADLESS, "--scene", scene_file, "--width", str(W), "--height", str(H), "--spp", str(spp), "--max-bounce", "4", *extra,
+            "--out", out_file, "--pos", *map(str, c["pos"]), "--target", *map(str, c["target"]),
+            "--fov", str(c["v_fov"]), "--aperture", str(c["aperture"]), "--focus", str(c["focus"])]
+
+
+@pytest.mark.parametrize("ranks,transport", [(2, "file"), (3, "file"), (1, "rccl")])
+def test_headless_tile_partition_over_processes(tmp_path, ranks, transport):
+    """--gpus N --partition tiles: N processes (here all on the one GPU, exchanging through the file transport -- RCCL refuses
+    two ranks on a device -- or one process running the RCCL all-gather alone), each rendering its stripes, one all-gather:
+    the merged image equals the oracle's whole frame bit for bit."""
+    W, H, SPP = 72, 44, 3                                             # 44 rows: the last stripe is ragged
+    b = make_bundle("atrium", 3000, W, H, max_bounce=4)
+    scene_file = str(tmp_path / "scene.ptrscene")
+    out_file = str(tmp_path / "out.pfm")
+    scenes.save_ptrscene(b, scene_file)
+    r = subprocess.run(headless_cmd(b, scene_file, out_file, W, H, SPP, "--gpus", str(ranks), "--partition", "tiles", "--transport", transport),
+                       capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0, r.stderr
+    assert r.stderr.count(f"of {ranks}, tiles over {transport}") == ranks, r.stderr
+    ref, _, _ = oracle_frames(b, SPP, use_flat=True)
+    img = read_ptrf(out_file)
+    assert np.array_equal(img, ref), f"{int((np.abs(img - ref).max(axis=2) > 0).sum())} pixels differ\n{r.stderr}"
+
+
+@pytest.mark.parametrize("ranks,transport", [(2, "file"), (1, "rccl")])
+def test_headless_sample_partition_over_processes(tmp_path, ranks, transport):
+    """--partition samples: every rank keeps the running mean of its own global samples; linearise, all-reduce, resolve.
+    Expected value from the oracle: each rank's frames with that rank's sample numbers, then the same three steps."""
+    import ctypes as C
+    import pyoracle
+    W, H, SPP = 56, 40, 4
+    b = make_bundle("atrium", 3000, W, H, max_bounce=4)
+    scene_file = str(tmp_path / "scene.ptrscene")
+    out_file = str(tmp_path / "out.pfm")
+    scenes.save_ptrscene(b, scene_file)
+    r = subprocess.run(headless_cmd(b, scene_file, out_file, W, H, SPP, "--gpus", str(ranks), "--partition", "samples", "--transport", transport),
+                       capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0, r.stderr
+    L = pyoracle.lib()
+    total = np.zeros((H, W, 4), np.float32)
+    for rank in range(ranks):
+        o = pyoracle.OracleScene(b)
+        acc = np.zeros((H, W, 4), np.float32)
+        out = np.zeros_like(acc)
+        for k in range(1, SPP // ranks + 1):
+            o.set_meta(sample_index=k)
+            o.seed_sample_index = (k - 1) * ranks + rank + 1
+            o.render(acc, out, use_flat=True)
+            acc, out = out, acc
+        lin = np.ones_like(acc)
+        for y in range(H):
+            for x in range(W):
+                L.orc_srgb_to_linear(acc[y, x, :3].ctypes.data_as(C.c_void_p), lin[y, x, :3].ctypes.data_as(C.c_void_p))
+        total += lin                                                 # rank order, like the transports
+    want = np.ones_like(total)
+    mean = (total[..., :3] / total[..., 3:4]).astype(np.float32)
+    for y in range(H):
+        for x in range(W):
+            L.orc_linear_to_srgb(mean[y, x].ctypes.data_as(C.c_void_p), want[y, x, :3].ctypes.data_as(C.c_void_p))
+    img = read_ptrf(out_file)
+    assert np.array_equal(img, want), f"{int((np.abs(img - want).max(axis=2) > 0).sum())} pixels differ\n{r.stderr}"
+
+
 def test_headless_reports_errors():
     r = subprocess.run([HEADLESS, "--scene", "/nonexistent.ptrscene"], capture_output=True, text=True, timeout=60)
     assert r.returncode == 1 and "cannot open" in r.stderr
