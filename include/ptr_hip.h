@@ -176,6 +176,18 @@ int ptr_set_sample_partition(ptr_ctx* ctx, uint32_t rank, uint32_t world);
  *                              ptr_buffer_write to them) the library checks on the GPU that every vertex id, material id,
  *                              node link and child reference stays inside the buffer it indexes, and fails the dispatch with
  *                              PTR_E_RANGE otherwise (one synchronisation per upload); 0: trust the caller.
+ *      "dispatch.samples"      1 (default) .. 16: a "compute" dispatch of the wavefront pipeline renders that many consecutive
+ *                              samples -- sample_index, sample_index + 1, ... of the metadata -- in one pass through the kernels
+ *                              (every tile is queued that many times) and accumulates them in order; the output image then
+ *                              holds what that many single-sample dispatches, with the caller's image swap after each
+ *                              (src/main.cpp:416), would have left in the image written last, bit for bit, and the caller
+ *                              advances sample_index by the same number.  An extension of the frame protocol for callers
+ *                              that want samples rather than every intermediate frame (progressive accumulation, the
+ *                              benchmark): a launch then holds several times the rays, so the drain of each persistent
+ *                              launch and the launch boundaries weigh less, and a GPU that owns 1/N of the pixels in the
+ *                              tile partition still has a full GPU's worth of rays.  Needs output and accumulation images of
+ *                              the same extent; not available with ptr_set_capture, the megakernel or debug_bvh
+ *                              (PTR_E_UNSUPPORTED / PTR_E_STATE).
  *      "shade.pregather"       1 (default): the wavefront shade step reads one 80-byte record per hit triangle (vertex
  *                              normals, uvs, material id, geometry normal) that the library gathers once from the index /
  *                              positions / normals / uvs buffers of the dispatch and re-gathers after any ptr_buffer_write

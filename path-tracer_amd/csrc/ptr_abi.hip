@@ -100,6 +100,7 @@ struct ptr_ctx {
     int opt_extend_refill = 16;     // idle lanes that trigger a refill of the traversal wave (8, 16, 32, 48, 64)
     int opt_extend_blocks_per_cu = 6;
     int opt_index_words = 3;        // layout of the index buffer: 3 = the reference's packed words, 4 = v0, v1, v2, material
+    int opt_dispatch_samples = 1;   // samples one "compute" dispatch of the wavefront pipeline renders (sample_index, +1, ...)
     int opt_shade_pregather = 1;    // wavefront shade reads per-triangle records gathered once per scene
     // the records, and what they were built from: addresses + write generations of indices / positions / normals / uvs
     void* shade_records = nullptr;
@@ -521,6 +522,7 @@ int dispatch_compute(ptr_ctx* c, const uint8_t constants[64], uint32_t gx, uint3
         sv.capture = (ptr::Capture*)cb->ptr;
     }
     sv.stats = c->stats_on ? c->d_stats : nullptr;
+    sv.batch_samples = (uint32_t)c->opt_dispatch_samples;
 
     BufferRec* bvh_buf = &c->buffers[handles[1]];
     BufferRec* flat_buf = bvh_buf->flat ? find_buffer(c, bvh_buf->flat) : nullptr;
@@ -536,7 +538,17 @@ int dispatch_compute(ptr_ctx* c, const uint8_t constants[64], uint32_t gx, uint3
             return fail(c, PTR_E_UNSUPPORTED, "debug_bvh: not defined for placed copies (the threaded tree has no instancing)");
         wavefront = false;
     }
-    if (c->stats_on) c->stats_frames++;
+    if (sv.batch_samples > 1u) {
+        // several samples per dispatch exist in the wavefront pipeline only; their accumulate chain runs in registers
+        if (!wavefront) return fail(c, PTR_E_UNSUPPORTED, "dispatch.samples > 1: only the wavefront pipeline renders several samples per dispatch (the megakernel and the debug_bvh heat-map do one)");
+        if (sv.capture) return fail(c, PTR_E_STATE, "dispatch.samples > 1: the per-pixel capture holds one sample's hits; set dispatch.samples to 1");
+        const ImageRec& oi = c->images[k.output_index];
+        const ImageRec& ai = c->images[k.accumulation_index];
+        if (oi.w != ai.w || oi.h != ai.h) return fail(c, PTR_E_STATE, "dispatch.samples > 1: the output and accumulation images must have the same extent");
+        if ((uint64_t)meta.width * meta.height * sv.batch_samples >= (1ull << 31)) return fail(c, PTR_E_RANGE, "dispatch.samples x width x height must stay below 2^31");
+        if (meta.sample_index > 0xffffffffu - sv.batch_samples) return fail(c, PTR_E_RANGE, "sample_index + dispatch.samples overflows");
+    }
+    if (c->stats_on) c->stats_frames += sv.batch_samples;
 
     if (!wavefront) {
         // the threaded walk starts at node 0: at least one node must be there
@@ -616,7 +628,7 @@ int dispatch_compute(ptr_ctx* c, const uint8_t constants[64], uint32_t gx, uint3
 
     // queue slots: whole 8x8 tiles of the owned rows (padded by one stripe); samples are indexed by pixel
     const uint32_t padded = ((meta.width + 7u) / 8u) * ((meta.height + 7u) / 8u + c->part_stripe / 8u) * 64u;
-    const uint32_t paths = padded > meta.width * meta.height ? padded : meta.width * meta.height;
+    const uint32_t paths = (padded > meta.width * meta.height ? padded : meta.width * meta.height) * sv.batch_samples;
 
     if (no_alloc) {
         // one frame, start to end on the context's stream, in this GPU's fixed scratch array
@@ -1250,6 +1262,11 @@ int ptr_set_option(ptr_ctx* c, const char* key, int value) {
     if (!strcmp(key, "scene.validate")) {
         if (value != 0 && value != 1) return fail(c, PTR_E_INVALID, "scene.validate: 0 or 1");
         c->opt_validate = value;
+        return PTR_OK;
+    }
+    if (!strcmp(key, "dispatch.samples")) {
+        if (value < 1 || value > 16) return fail(c, PTR_E_INVALID, "dispatch.samples: 1..16");
+        c->opt_dispatch_samples = value;
         return PTR_OK;
     }
     if (!strcmp(key, "shade.pregather")) {

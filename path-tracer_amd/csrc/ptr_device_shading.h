@@ -60,6 +60,7 @@ struct SceneView {
     const float4* instance_records;  // optional (two-level scenes): 4 float4 per instance, rows of world-to-object first
     uint32_t instance_count;
     uint32_t object_triangles;       // two-level scenes: captured primitive ids read instance * object_triangles + primitive
+    uint32_t batch_samples;          // wavefront pipeline: samples meta.sample_index, +1, ... traced by ONE dispatch (>= 1)
 };
 
 struct Ray { f3 origin, dir; float min_t, max_t; };
@@ -418,6 +419,27 @@ PTR_DEV void image_store(const ImageDesc& im, int32_t x, int32_t y, f3 c) {
     if (im.data == nullptr || x < 0 || y < 0 || (uint32_t)x >= im.width || (uint32_t)y >= im.height) return;
     ((float4*)im.data)[(size_t)y * im.width + (size_t)x] = make_float4(c.x, c.y, c.z, 1.0f);
 }
+// The accumulate step of `count` consecutive frames on one pixel, samples[k * stride] being frame k's sample: what `count`
+// dispatches with the host's image swap in between (src/main.cpp:416) leave in the image written last.  Each frame decodes
+// what the frame before stored -- the encode / decode round trip is not the identity in fp32, so it is done, not skipped --
+// and a pixel outside the images reads 0 every time, as image_load gives it.  Both images must have the same extent.
+PTR_DEV void accumulate_pixel_chain(const ImageDesc& acc, const ImageDesc& out, int32_t cx, int32_t cy, int32_t downscale,
+                                    uint32_t first_sample_index, uint32_t count, const float4* samples, size_t stride) {
+    const f4 a = image_load(acc, cx, cy);
+    f3 stored = mk3(a.x, a.y, a.z);
+    const bool inside = out.data != nullptr && cx >= 0 && cy >= 0 && (uint32_t)cx < out.width && (uint32_t)cy < out.height;
+    f3 o = stored;
+    for (uint32_t k = 0; k < count; k++) {
+        const float4 s4 = samples[(size_t)k * stride];
+        const float spp_scale = 1.0f / (float)(first_sample_index + k);
+        const f3 prev = srgb_to_linear(stored);
+        o = linear_to_srgb(mk3(mixf(prev.x, s4.x, spp_scale), mixf(prev.y, s4.y, spp_scale), mixf(prev.z, s4.z, spp_scale)));
+        stored = inside ? o : mk3(0.0f, 0.0f, 0.0f);
+    }
+    for (int32_t i = 0; i < downscale; i++)
+        for (int32_t j = 0; j < downscale; j++) image_store(out, cx + i, cy + j, o);
+}
+
 PTR_DEV void accumulate_pixel(const ImageDesc& acc, const ImageDesc& out, int32_t cx, int32_t cy, int32_t downscale,
                               uint32_t sample_index, f3 sample) {
     const float spp_scale = 1.0f / (float)sample_index;

@@ -28,15 +28,19 @@ __global__ __launch_bounds__(256) void ptr_wf_generate(SceneView sv, WavefrontSc
     const SceneMeta& m = sv.meta;
     const uint32_t wave = blockIdx.x * 4u + (threadIdx.x >> 6);
     const uint32_t lane = threadIdx.x & 63u;
-    if (wave >= tiles_x * owned_tile_rows) return;
-    if (wave == 0u && lane == 0u) w.counters[0] = tiles_x * owned_tile_rows * 64u;
-    const uint32_t j = wave / tiles_x;  // j-th tile row owned by this GPU
+    // a dispatch of S samples queues every tile S times, the S copies next to each other: waves that run at the same time
+    // walk the same part of the tree
+    const uint32_t S = sv.batch_samples;
+    if (wave >= tiles_x * owned_tile_rows * S) return;
+    if (wave == 0u && lane == 0u) w.counters[0] = tiles_x * owned_tile_rows * S * 64u;
+    const uint32_t tile = wave / S, sample_in_batch = wave % S;
+    const uint32_t j = tile / tiles_x;  // j-th tile row owned by this GPU
     uint32_t tile_row = j;
     if (sv.part_world > 1u) {
         const uint32_t rows_per_stripe = sv.part_stripe_rows / 8u;
         tile_row = ((j / rows_per_stripe) * sv.part_world + sv.part_rank) * rows_per_stripe + j % rows_per_stripe;
     }
-    const uint32_t gx = (wave % tiles_x) * 8u + (lane & 7u);
+    const uint32_t gx = (tile % tiles_x) * 8u + (lane & 7u);
     const uint32_t gy = tile_row * 8u + (lane >> 3);
     const bool valid = gx < domain_w && gy < domain_h;
 
@@ -44,12 +48,14 @@ __global__ __launch_bounds__(256) void ptr_wf_generate(SceneView sv, WavefrontSc
     uint32_t seed = 0u;
     if (valid) {
         const int32_t cx = (int32_t)gx * m.downscale_factor, cy = (int32_t)gy * m.downscale_factor;
-        seed = pixel_seed(cx, cy, seed_sample_index(sv, m.sample_index));
+        seed = pixel_seed(cx, cy, seed_sample_index(sv, m.sample_index + sample_in_batch));
         r = generate_camera_ray(m, cx, cy, seed);  // seed by value: the bounce loop restarts from it
         if (sv.capture) { Capture c; c.prim0 = -1; c.t0 = 0.0f; c.prim1 = -1; c.t1 = 0.0f; sv.capture[(size_t)gy * m.width + gx] = c; }
     }
     const uint32_t slot = wave * 64u + lane;
-    w.ray_o[0][slot] = make_float4(r.origin.x, r.origin.y, r.origin.z, __uint_as_float(valid ? gy * m.width + gx : kInvalidPixel));
+    // a path names where its sample goes: sample k of the batch has its own width * height block of w.samples
+    w.ray_o[0][slot] = make_float4(r.origin.x, r.origin.y, r.origin.z,
+                                   __uint_as_float(valid ? sample_in_batch * (m.width * m.height) + gy * m.width + gx : kInvalidPixel));
     w.ray_d[0][slot] = make_float4(r.dir.x, r.dir.y, r.dir.z, __uint_as_float(seed));
     w.path_t[0][slot] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
 }
@@ -650,6 +656,12 @@ __global__ __launch_bounds__(256) void ptr_wf_accumulate(SceneView sv, Wavefront
     const uint32_t gx = (wave % tiles_x) * 8u + (lane & 7u);
     const uint32_t gy = (wave / tiles_x) * 8u + (lane >> 3);
     if (gx >= domain_w || gy >= domain_h || !owns_row(sv, gy)) return;
+    if (sv.batch_samples > 1u) {
+        accumulate_pixel_chain(sv.images[sv.accumulation_index], sv.images[sv.output_index], (int32_t)gx * m.downscale_factor,
+                               (int32_t)gy * m.downscale_factor, m.downscale_factor, m.sample_index, sv.batch_samples,
+                               w.samples + (gy * m.width + gx), (size_t)m.width * m.height);
+        return;
+    }
     const float4 s = w.samples[gy * m.width + gx];
     accumulate_pixel(sv.images[sv.accumulation_index], sv.images[sv.output_index], (int32_t)gx * m.downscale_factor,
                      (int32_t)gy * m.downscale_factor, m.downscale_factor, m.sample_index, mk3(s.x, s.y, s.z));
@@ -671,7 +683,7 @@ hipError_t launch_wf_generate(hipStream_t s, const SceneView& sv, const Wavefron
         const uint32_t owned = stripes > sv.part_rank ? (stripes - sv.part_rank + sv.part_world - 1u) / sv.part_world : 0u;
         owned_tile_rows = owned * rows_per_stripe;
     }
-    const uint32_t waves = tiles_x * owned_tile_rows;
+    const uint32_t waves = tiles_x * owned_tile_rows * sv.batch_samples;
     // the kernel publishes the queue length; with nothing owned, leave the zeroed counter alone
     if (waves == 0) return hipSuccess;
     hipLaunchKernelGGL(ptr_wf_generate, dim3((waves + 3u) / 4u), dim3(256), 0, s, sv, w, domain_w, domain_h, tiles_x, owned_tile_rows);
@@ -722,7 +734,7 @@ hipError_t launch_wf_extend(hipStream_t s, const FlatView& fv, const WavefrontSc
 hipError_t launch_wf_shade(hipStream_t s, const SceneView& sv, const WavefrontScratch& w, uint32_t bounce, uint32_t max_bounce,
                            uint32_t min_bounce, uint32_t domain_w, uint32_t domain_h) {
     // queue slots never exceed the padded tile count of the frame
-    const uint32_t upper = ((domain_w + 7u) / 8u) * ((domain_h + 7u) / 8u + sv.part_stripe_rows / 8u) * 64u;
+    const uint32_t upper = ((domain_w + 7u) / 8u) * ((domain_h + 7u) / 8u + sv.part_stripe_rows / 8u) * 64u * sv.batch_samples;
     const uint32_t blocks = (upper + kShadeThreads - 1u) / kShadeThreads;
     if (blocks == 0) return hipSuccess;
     const uint32_t slot_b = bounce % kMaxBounceSlots, slot_next = (bounce + 1u) % kMaxBounceSlots;

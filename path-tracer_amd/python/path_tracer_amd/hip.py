@@ -419,8 +419,11 @@ class FrameLoop:
     """The reference's per-frame protocol (src/main.cpp:406-416) without a window: set the output texture
     and the accumulation constant, execute, advance sample_index, swap the two images."""
 
-    def __init__(self, ctx, scene, width, height, pipeline="compute", textures=None):
+    def __init__(self, ctx, scene, width, height, pipeline="compute", textures=None, samples_per_dispatch=1):
         self.ctx, self.scene, self.width, self.height = ctx, scene, width, height
+        # > 1: one dispatch renders that many consecutive samples ("dispatch.samples", wavefront pipeline only); the images
+        # swap once per dispatch and the result equals that many single-sample frames
+        self.samples_per_dispatch = samples_per_dispatch
         if textures is None:
             self.accumulation = ctx.create_2d_texture(width, height, FORMAT_RGBA32_SFLOAT)
             self.output = ctx.create_2d_texture(width, height, FORMAT_RGBA32_SFLOAT)
@@ -435,13 +438,26 @@ class FrameLoop:
     def reset(self):
         self.sample_index = 1
 
-    def frame(self):
+    def frame(self, samples=1):
+        """One dispatch of `samples` consecutive samples (1 = the reference's protocol)."""
+        self.ctx.set_option("dispatch.samples", samples)
         self.scene.update_meta(sample_index=self.sample_index)
         self.renderpass.set_ouput_texture(self.output)
         self.renderpass.set_constant(60, self.accumulation)
-        self.renderpass.execute()
-        self.sample_index += 1
+        try:
+            self.renderpass.execute()
+        finally:
+            if samples != 1:
+                self.ctx.set_option("dispatch.samples", 1)
+        self.sample_index += samples
         self.output, self.accumulation = self.accumulation, self.output
+
+    def frames(self, count):
+        """`count` samples, `samples_per_dispatch` at a time (the last dispatch takes what is left)."""
+        while count > 0:
+            n = min(count, self.samples_per_dispatch)
+            self.frame(n)
+            count -= n
 
     def latest(self):
         """The image the last frame wrote (after the swap it is `accumulation`)."""

@@ -59,13 +59,15 @@ def main():
     for rnd in range(args.rounds + 1):
         for i, cfg in enumerate(configs):
             for k, v in cfg.items():
-                ctx.set_option(k, v)
+                if k == "dispatch.samples":              # the frame loop sets this one per dispatch
+                    loop.samples_per_dispatch = v
+                else:
+                    ctx.set_option(k, v)
             loop.reset()
-            loop.frame(); ctx.sync()                     # settle (scratch re-allocation, clocks)
+            loop.frames(loop.samples_per_dispatch); ctx.sync()   # settle (scratch re-allocation, clocks)
             ctx.profile_read(reset=True); ctx.profile_enable(not args.no_profile)
             t0 = time.perf_counter()
-            for _ in range(args.frames):
-                loop.frame()
+            loop.frames(args.frames)
             ctx.sync()
             dt = (time.perf_counter() - t0) / args.frames * 1e3
             ctx.profile_enable(False)

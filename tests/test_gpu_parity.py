@@ -624,3 +624,94 @@ def test_full_size_properties_1080p(ctx):
         acc, out = out, acc
     for y0, y1 in rows:
         assert_same(wf1[y0:y1], acc[y0:y1], f"rows {y0}:{y1} vs oracle")
+
+
+@pytest.mark.parametrize("kind,target,w,h,meta_kw", [("tiny", 0, 50, 37, dict(max_bounce=5)), ("atrium", 5000, 96, 54, dict(max_bounce=4)),
+                                                     ("tiny", 0, 40, 24, dict(max_bounce=3, downscale_factor=2, enable_dof=1))])
+def test_several_samples_per_dispatch_equal_as_many_single_sample_frames(ctx, kind, target, w, h, meta_kw):
+    """"dispatch.samples" = S: one pass through the kernels for S samples, their accumulate chain in registers.  Seven
+    samples as 3 + 3 + 1 and as 4 + 2 + 1 against the oracle's seven sequential frames, bit for bit; the counting variant
+    sees the same rays, nodes and triangles as the oracle summed over the batch."""
+    from path_tracer_amd import hip
+    import pyoracle
+    b = make_bundle(kind, target, w, h, **meta_kw)
+    gs = hip.GpuScene(ctx, b, b["nodes"], b["flat"], b["meta"])
+    ref, _, _ = oracle_for(b, gs, 7, use_flat=True)
+    for per_dispatch in (3, 4):
+        gs.set_meta(b["meta"])
+        loop = hip.FrameLoop(ctx, gs, w, h, "compute", samples_per_dispatch=per_dispatch)
+        loop.frames(per_dispatch)
+        loop.frames(7 - per_dispatch)
+        assert loop.sample_index == 8
+        assert_same(loop.latest().read(), ref, f"{per_dispatch} samples per dispatch")
+    # work counters of one batch of three = the oracle's three frames added up
+    gs.set_meta(b["meta"])
+    loop = hip.FrameLoop(ctx, gs, w, h, "compute", samples_per_dispatch=3)
+    ctx.stats_read(reset=True); ctx.stats_enable(True)
+    loop.frames(3)
+    st = ctx.stats_read(reset=True); ctx.stats_enable(False)
+    o = pyoracle.OracleScene(dict(b, materials=gs.materials_host, textures=gs.texture_table))
+    acc = np.zeros((h, w, 4), np.float32); out = np.zeros_like(acc)
+    want = dict(rays=0, nodes=0, triangles=0, shaded=0)
+    for s in (1, 2, 3):
+        o.set_meta(sample_index=s)
+        c = o.render(acc, out, use_flat=True)
+        acc, out = out, acc
+        for k in want:
+            want[k] += c[k]
+    assert {k: st[k] for k in want} == want and st["frames"] == 3
+
+
+def test_several_samples_per_dispatch_with_the_partitions_and_where_it_is_refused(ctx):
+    from path_tracer_amd import hip
+    b = make_bundle("atrium", 4000, 80, 72, max_bounce=3)
+    gs = hip.GpuScene(ctx, b, b["nodes"], b["flat"], b["meta"])
+    whole, _, _ = oracle_for(b, gs, 4, use_flat=True)
+    rows = (np.arange(72) // 8) % 2
+    merged = np.zeros_like(whole)
+    try:
+        for rank in range(2):                                       # tile partition: each rank's stripes, four samples in one dispatch
+            ctx.set_partition(rank, 2, 8)
+            gs.set_meta(b["meta"])
+            loop = hip.FrameLoop(ctx, gs, 80, 72, "compute", samples_per_dispatch=4)
+            loop.frames(4)
+            part = loop.latest().read()
+            assert (part[rows != rank] == 0).all()
+            merged[rows == rank] = part[rows == rank]
+    finally:
+        ctx.set_partition(0, 1, 8)
+    assert_same(merged, whole, "tile partition, 4 samples per dispatch")
+    try:                                                            # sample partition: rank 1 of 3 draws the global samples 2, 5, 8, 11
+        ctx.set_sample_partition(1, 3)
+        gs.set_meta(b["meta"])
+        loop = hip.FrameLoop(ctx, gs, 80, 72, "compute", samples_per_dispatch=2)
+        loop.frames(4)
+        got = loop.latest().read()
+    finally:
+        ctx.set_sample_partition(0, 1)
+    import pyoracle
+    o = pyoracle.OracleScene(dict(b, materials=gs.materials_host, textures=gs.texture_table))
+    acc = np.zeros((72, 80, 4), np.float32); out = np.zeros_like(acc)
+    for k in range(1, 5):
+        o.set_meta(sample_index=k)
+        o.seed_sample_index = (k - 1) * 3 + 1 + 1
+        o.render(acc, out, use_flat=True)
+        acc, out = out, acc
+    assert_same(got, acc, "sample partition, 2 samples per dispatch")
+    # refused: the strict drop-in kernel, the heat-map, the per-pixel capture
+    gs.set_meta(b["meta"])
+    with pytest.raises(hip.HipError, match="dispatch.samples"):
+        hip.FrameLoop(ctx, gs, 80, 72, "compute.megakernel").frame(2)
+    gs.update_meta(debug_bvh=1)
+    with pytest.raises(hip.HipError, match="dispatch.samples"):
+        hip.FrameLoop(ctx, gs, 80, 72, "compute").frame(2)
+    gs.update_meta(debug_bvh=0)
+    cap = ctx.create_buffer(80 * 72 * 16)
+    ctx.set_capture(cap)
+    try:
+        with pytest.raises(hip.HipError, match="capture"):
+            hip.FrameLoop(ctx, gs, 80, 72, "compute").frame(2)
+    finally:
+        ctx.set_capture(None)
+        cap.destroy()
+    hip.FrameLoop(ctx, gs, 80, 72, "compute").frame(2)             # and fine again afterwards
