@@ -199,6 +199,9 @@ def make_parser():
     ap.add_argument("--frames-in-flight", type=int, default=2, help="consecutive frames overlapped on internal streams (1 = none)")
     ap.add_argument("--partition", default="tiles", choices=["tiles", "samples"], help="how N > 1 GPUs share the work (see the module text)")
     ap.add_argument("--stripe-rows", type=int, default=8, help="tile partition: image rows per stripe (a multiple of 8)")
+    ap.add_argument("--samples-per-dispatch", type=int, default=16,
+                    help="upper bound of the samples (= steps) one dispatch renders (\"dispatch.samples\"): the K steps are dealt evenly to "
+                         "ceil(K / this) dispatches; the image equals K single-sample dispatches bit for bit.  1 = the reference's one dispatch per sample")
     return ap
 
 
@@ -405,7 +408,11 @@ def main():
         tex_a = ctx.wrap_2d_texture(img_a.data_ptr(), W, H)
         tex_b = ctx.wrap_2d_texture(img_b.data_ptr(), W, H)
         by_handle = {tex_a.handle: img_a, tex_b.handle: img_b}
-        loop = hip.FrameLoop(ctx, gpu, W, H, args.pipeline, textures=(tex_a, tex_b))
+        # K steps in ceil(K / S) dispatches of (nearly) equal size
+        def per_dispatch(steps):
+            limit = 1 if args.pipeline == "compute.megakernel" else max(1, min(16, args.samples_per_dispatch))
+            return max(1, -(-steps // -(-steps // limit)))
+        loop = hip.FrameLoop(ctx, gpu, W, H, args.pipeline, textures=(tex_a, tex_b), samples_per_dispatch=per_dispatch(args.steps))
 
         def set_partition(on):
             if world > 1 and tiles:
@@ -456,16 +463,17 @@ def main():
             img_a.zero_(); img_b.zero_()
             barrier()
             t0 = time.perf_counter()
-            for _ in range(steps):
-                loop.frame()
+            loop.frames(steps)
             final = combine() if with_exchange else by_handle[loop.latest().handle]
             torch.cuda.synchronize()
             if multi:
                 dist.barrier()
             return time.perf_counter() - t0, final
 
-        for _ in range(args.warmup):
-            loop.frame()
+        # Untimed warm-up: the W steps asked for, and at least one dispatch of the timed size on each frame slot -- a slot's
+        # scratch is sized by the largest dispatch it has seen, and growing it (hipFree + hipMalloc) belongs to set-up
+        warmup_steps = max(args.warmup, args.frames_in_flight * loop.samples_per_dispatch)
+        loop.frames(warmup_steps)
         if multi:
             combine()
         barrier()
@@ -485,6 +493,18 @@ def main():
             loop.latest().read()
         build_times["frame_readback_ms"] = (time.perf_counter() - t_rb) / 3 * 1e3
 
+        # the same K steps the way the reference's frame loop issues them: one dispatch per sample
+        single_ms = None
+        if loop.samples_per_dispatch > 1:
+            keep = loop.samples_per_dispatch
+            loop.samples_per_dispatch = 1
+            single_elapsed, _ = timed(args.steps, multi)
+            loop.samples_per_dispatch = keep
+            t_single = torch.tensor([single_elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+            if multi:
+                dist.all_reduce(t_single, op=dist.ReduceOp.MAX)
+            single_ms = float(t_single.item()) / args.steps * 1e3
+
         # strong scaling needs the one-GPU time of the SAME total work on the same hardware: every rank renders the whole
         # frames alone (no partition, no exchange), outside the timed region
         t1_elapsed = None
@@ -498,8 +518,7 @@ def main():
         ctx.set_option("frames.in_flight", 1)
         ctx.profile_enable(True)
         solo_frames = args.steps              # the same sample indices as the timed frames: a frame's cost depends on its sample index
-        for _ in range(solo_frames):
-            loop.frame()
+        loop.frames(solo_frames)
         torch.cuda.synchronize()
         ctx.profile_enable(False)
         solo = ctx.profile_read(reset=True)
@@ -509,8 +528,7 @@ def main():
         loop.reset()
         ctx.stats_read(reset=True)
         ctx.stats_enable(True)
-        for _ in range(args.steps):
-            loop.frame()
+        loop.frames(args.steps)
         stats = ctx.stats_read(reset=True)
         ctx.stats_enable(False)
         torch.cuda.synchronize()
@@ -526,6 +544,12 @@ def main():
 
         if rank == 0:
             line = result_line(args, sc, W, H, world, tiles, elapsed, t1_elapsed, rays_total, stats, prof, solo, solo_frames, build_times)
+            line["config"]["samples_per_dispatch"] = loop.samples_per_dispatch
+            line["config"]["dispatches_per_gpu"] = -(-args.steps // loop.samples_per_dispatch)
+            line["config"]["warmup_steps_run"] = warmup_steps
+            if single_ms is not None:
+                line["one_sample_per_dispatch"] = {"ms_per_step": single_ms, "value": rays_total / (single_ms * 1e-3 * args.steps) / 1e6, "unit": "Mrays/s",
+                                                    "note": "the same K steps as K dispatches of one sample each (the reference's frame protocol), same partition and exchange, outside the timed region"}
             if timed_image is not None and args.pipeline != "compute.megakernel" and flat is not None and args.cpu_seconds > 0:
                 line["parity_check"] = parity_check(sc, nodes, flat, meta, gpu, timed_image, args.steps)
                 log(rank, "parity_check:", line["parity_check"])

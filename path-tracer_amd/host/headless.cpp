@@ -5,6 +5,7 @@
 //   ptr_headless --scene file.{ptrscene,gltf,glb} [--apply-transforms | --instanced] [--gpu-bvh] [--copies NX NZ] --width W --height H --spp N [--max-bounce B] [--min-bounce B]
 //                [--dof 0|1] [--downscale D] [--debug-bvh 0|1] [--pipeline compute|compute.megakernel|compute.wavefront]
 //                [--pos x y z] [--target x y z] [--fov deg] [--aperture a] [--focus f] [--out image.pfm|image.ppm|image.png]
+//                [--samples-per-dispatch S]   (1..16: one dispatch renders S consecutive samples, same image, fewer launches)
 //                [--gpus N [--partition tiles|samples] [--transport rccl|file] [--stripe-rows S] [--rendezvous DIR]]
 //
 // --gpus N (no counterpart in the single-device reference): the process starts N copies of itself, one per GPU, each with
@@ -15,6 +16,7 @@
 #include <sys/wait.h>
 #include <unistd.h>
 
+#include <algorithm>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -101,7 +103,7 @@ int main(int argc, char** argv) {
     std::string scene_path, out_path, pipeline = "compute";
     bool apply_transforms = false, gpu_bvh = false, instanced = false;
     uint32_t copies_x = 1, copies_z = 1;
-    uint32_t gpus = 1, stripe_rows = 8;
+    uint32_t gpus = 1, stripe_rows = 8, samples_per_dispatch = 1;
     int rank = -1, device = -1;
     bool transport_given = false;   // with --gpus 1: run the exchange anyway, alone (rehearses the RCCL calls on a one-GPU box)
     std::string partition = "tiles", transport = "rccl", rendezvous;
@@ -123,6 +125,7 @@ int main(int argc, char** argv) {
         else if (is("--transport")) { transport = next(); transport_given = true; }
         else if (is("--rendezvous")) rendezvous = next();
         else if (is("--stripe-rows")) stripe_rows = (uint32_t)std::atoi(next());
+        else if (is("--samples-per-dispatch")) samples_per_dispatch = (uint32_t)std::atoi(next());
         else if (is("--out")) out_path = next();
         else if (is("--pipeline")) pipeline = next();
         else if (is("--width")) width = (uint32_t)std::atoi(next());
@@ -183,16 +186,22 @@ int main(int argc, char** argv) {
         raytracing_pass->set_dispatch_size(width / 8 + 1, height / 8 + 1, 1);
 
         const auto t0 = std::chrono::steady_clock::now();
-        for (uint32_t frame = 0; frame < frames; frame++) {
+        if (samples_per_dispatch == 0 || samples_per_dispatch > 16) throw std::runtime_error("--samples-per-dispatch: 1..16");
+        for (uint32_t frame = 0; frame < frames;) {
+            // one dispatch = the next `batch` samples, accumulated in order; the images swap once per dispatch
+            const uint32_t batch = std::min(samples_per_dispatch, frames - frame);
+            hiprenderer::check(ptr_set_option(hiprenderer::api, "dispatch.samples", (int)batch), "ptr_set_option");
             raytracing_pass->set_ouput_texture(output_texture);
             raytracing_pass->set_constant(60, accumulation_texture);
             renderer.begin_frame();
             main_scene.upload_metadata();
             renderer.render();
-            main_scene.meta.sample_index++;
+            main_scene.meta.sample_index += batch;
+            frame += batch;
             std::swap(output_texture, accumulation_texture);
             renderer.finish_frame();
         }
+        hiprenderer::check(ptr_set_option(hiprenderer::api, "dispatch.samples", 1), "ptr_set_option");
         if (exchange && tiles) {
             // one all-gather of the owned stripes; after the swap the last written image is `accumulation_texture`
             const size_t chunk_bytes = stripe_chunk_texels(width, height, stripe_rows, gpus) * 16;

@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--texture-size", type=int, default=512)
     ap.add_argument("--pipeline", default="compute")
     ap.add_argument("--option", action="append", default=[])
+    ap.add_argument("--samples-per-dispatch", type=int, default=1)
     args = ap.parse_args()
     import bench
     from path_tracer_amd import hip
@@ -30,9 +31,8 @@ def main():
         k, v = kv.split("=")
         ctx.set_option(k, int(v))
     gpu = hip.GpuScene(ctx, sc, nodes, flat, meta)
-    loop = hip.FrameLoop(ctx, gpu, args.width, args.height, args.pipeline)
-    for _ in range(args.frames):
-        loop.frame()
+    loop = hip.FrameLoop(ctx, gpu, args.width, args.height, args.pipeline, samples_per_dispatch=args.samples_per_dispatch)
+    loop.frames(args.frames)
     ctx.sync()
     print("rendered", args.frames, "frames; mean of last image", float(loop.latest().read()[..., :3].mean()))
     ctx.close()

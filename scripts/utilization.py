@@ -8,6 +8,7 @@ ap.add_argument("--triangles", type=int, default=2_800_000); ap.add_argument("--
 ap.add_argument("--width", type=int, default=1920); ap.add_argument("--height", type=int, default=1080)
 ap.add_argument("--texture-size", type=int, default=512); ap.add_argument("--bounces", type=int, default=4)
 ap.add_argument("--set", nargs="*", default=[], help="library options, key=value")
+ap.add_argument("--samples-per-dispatch", type=int, default=1)
 ap.add_argument("--instances", default="1x1"); ap.add_argument("--two-level", action="store_true")
 args = ap.parse_args()
 import bench
@@ -22,7 +23,7 @@ prev = None
 for mb in range(1, args.bounces + 1):
     gpu.update_meta(max_bounce=mb)
     loop.reset(); ctx.stats_read(reset=True); ctx.stats_enable(True)
-    loop.frame()
+    loop.frame(args.samples_per_dispatch)
     st = ctx.stats_read(reset=True); ctx.stats_enable(False)
     cur = st
     if prev is not None:

@@ -135,6 +135,19 @@ def headless_cmd(b, scene_file, out_file, W, H, spp, *extra):
             "--fov", str(c["v_fov"]), "--aperture", str(c["aperture"]), "--focus", str(c["focus"])]
 
 
+def test_headless_several_samples_per_dispatch(tmp_path):
+    """--samples-per-dispatch 3 with --spp 7 (3 + 3 + 1): the image of seven single-sample frames."""
+    W, H, SPP = 72, 40, 7
+    b = make_bundle("atrium", 3000, W, H, max_bounce=4)
+    scene_file = str(tmp_path / "scene.ptrscene")
+    out_file = str(tmp_path / "out.pfm")
+    scenes.save_ptrscene(b, scene_file)
+    r = subprocess.run(headless_cmd(b, scene_file, out_file, W, H, SPP, "--samples-per-dispatch", "3"), capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    ref, _, _ = oracle_frames(b, SPP, use_flat=True)
+    assert np.array_equal(read_ptrf(out_file), ref)
+
+
 @pytest.mark.parametrize("ranks,transport", [(2, "file"), (3, "file"), (1, "rccl")])
 def test_headless_tile_partition_over_processes(tmp_path, ranks, transport):
     """--gpus N --partition tiles: N processes (here all on the one GPU, exchanging through the file transport -- RCCL refuses
