@@ -28,6 +28,11 @@ sys.path.insert(0, os.path.join(ROOT, "path-tracer_amd", "python"))
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak
+# VALU issue peak: 256 CUs x 4 SIMDs x 16 lanes per cycle at the 2.4 GHz peak engine clock, in lane-instructions per second
+VALU_PEAK_TLANE = 256 * 4 * 16 * 2.4e9 / 1e12
+# VALU instructions of one 4-wide node step (four quantised box tests, sort, push) and of one triangle test on their common
+# paths in the compiled traversal kernel (counted in the gfx950 ISA of csrc/ptr_kernels_wavefront.hip)
+VALU_PER_NODE, VALU_PER_TRIANGLE = 128, 67
 
 
 def log(rank, *a):
@@ -162,7 +167,7 @@ def lavapipe_probe():
     return "available (not driven by this benchmark)" if not missing else "unavailable: " + ", ".join(missing)
 
 
-def pmc_traffic(kernel, workload):
+def pmc_traffic(kernel, workload, samples_per_dispatch=None):
     """HBM bytes per launch of `kernel` from the committed counter passes of this same command (profiles/traffic.json,
     written by scripts/traffic_from_pmc.py): FETCH_SIZE and WRITE_SIZE come from separate rocprofv3 --pmc runs, so
     they cannot be collected inside this process.  None when the file is missing or was measured on another workload."""
@@ -173,10 +178,15 @@ def pmc_traffic(kernel, workload):
     except (OSError, ValueError):
         return None, "no profiles/traffic.json", {}
     rec = t.get("kernels", {}).get(kernel)
-    if rec is None or t.get("workload") != workload:
-        return None, "profiles/traffic.json holds no counters for this kernel and workload", {}
+    if samples_per_dispatch is None:
+        samples_per_dispatch = pmc_traffic.samples_per_dispatch
+    if rec is None or t.get("workload") != workload or t.get("samples_per_dispatch", 1) != samples_per_dispatch:
+        return None, "profiles/traffic.json holds no counters for this kernel, workload and dispatch size", {}
     extra = {k: rec[k] for k in ("valu_busy", "l2_hit_rate", "l1_hit_rate", "waves_waiting") if k in rec}
     return rec["bytes_per_launch"], t.get("note", ""), extra
+
+
+pmc_traffic.samples_per_dispatch = 1   # set by main(): launches of another size move other byte counts
 
 
 def make_parser():
@@ -275,6 +285,15 @@ def result_line(args, sc, W, H, world, tiles, elapsed, t1_elapsed, rays_total, s
                               "frac": (solo_bytes / (ks["total_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS) if ks["total_ms"] > 0 else 0.0},
                      # the whole step against the clock: every kernel's algorithmic bytes / ms_per_step
                      "frame_level": None},
+        # The roofline that does bind the traversal kernel on a cache-resident scene: VALU issue.  Algorithmic lane-instructions
+        # (node steps and triangle tests only: no bookkeeping, every lane counted as useful) over the solo launch time, against
+        # what the SIMDs can issue.  The gap to 1 is lanes without work in a step (lane_utilisation, leaf / inner divergence),
+        # cycles without issue (counters.valu_busy) and the instructions around the two step bodies.
+        "valu_roofline": ({"kernel": dominant, "bound": "valu", "unit": "Tlane-instr/s", "peak": VALU_PEAK_TLANE,
+                           "achieved": (VALU_PER_NODE * stats["nodes"] + VALU_PER_TRIANGLE * stats["triangles"]) * (ks["launches"] / max(1, k["launches"]) if k["launches"] else 1.0)
+                                       / (ks["total_ms"] * 1e-3) / 1e12 if ks["total_ms"] > 0 else 0.0,
+                           "instructions_per_unit": {"node": VALU_PER_NODE, "triangle": VALU_PER_TRIANGLE},
+                           "denominator": "solo launches (one dispatch in flight)"} if wavefront else None),
         "kernels_ms_per_step_solo": {n: v["total_ms"] / solo_frames for n, v in sorted(solo.items()) if v["launches"]},
         "setup": build_times,
     }
@@ -283,7 +302,8 @@ def result_line(args, sc, W, H, world, tiles, elapsed, t1_elapsed, rays_total, s
         paths = stats["rays"]                        # one path record per ray traced
         survivors = max(0, stats["rays"] - pixels)   # rays of bounce >= 1 are the survivors some shade launch wrote
         shade_bytes = 64 * paths + 48 * survivors + (80 + 48 + 32) * stats["shaded"] + 16 * pixels
-        acc_bytes = (32 + 16) * pixels
+        dispatches = -(-args.steps // max(1, pmc_traffic.samples_per_dispatch))
+        acc_bytes = 16 * pixels + 32 * (pixels // args.steps) * dispatches   # every sample is read; the images once per dispatch
         gen_bytes = 48 * pixels
         others = []
         if solo.get("wavefront.shade", {}).get("launches"):
@@ -291,13 +311,15 @@ def result_line(args, sc, W, H, world, tiles, elapsed, t1_elapsed, rays_total, s
                                           "per path 64 B (origin, direction, throughput, hit) + per survivor 48 B written + per shaded hit 80 B record + 48 B material + 2 x 4 texels + 16 B sample per finished path"))
         if solo.get("wavefront.accumulate", {}).get("launches"):
             others.append(kernel_roofline("wavefront.accumulate", acc_bytes, solo["wavefront.accumulate"], line_workload,
-                                          "per pixel 16 B accumulation read + 16 B output write + 16 B sample read"))
+                                          "per sample 16 B sample read; per dispatch and pixel 16 B accumulation read + 16 B output write"))
         if solo.get("wavefront.generate", {}).get("launches"):
             others.append(kernel_roofline("wavefront.generate", gen_bytes, solo["wavefront.generate"], line_workload, "per pixel 48 B of queue records written"))
         line["roofline"]["other_kernels_solo"] = others
         total = algo_bytes + shade_bytes + acc_bytes + gen_bytes
         line["roofline"]["frame_level"] = {"algorithmic_bytes_per_step": total / args.steps, "achieved": total / elapsed / 1e9,
                                            "frac": total / elapsed / 1e9 / HBM_PEAK_GBS}
+    if line.get("valu_roofline"):
+        line["valu_roofline"]["frac"] = line["valu_roofline"]["achieved"] / VALU_PEAK_TLANE
     if world > 1 and tiles and t1_elapsed:
         line["strong_scaling"] = {"t1_ms_per_step": t1_elapsed / args.steps * 1e3, "tn_ms_per_step": elapsed / args.steps * 1e3,
                                   "efficiency": t1_elapsed / (world * elapsed),
@@ -413,6 +435,7 @@ def main():
             limit = 1 if args.pipeline == "compute.megakernel" else max(1, min(16, args.samples_per_dispatch))
             return max(1, -(-steps // -(-steps // limit)))
         loop = hip.FrameLoop(ctx, gpu, W, H, args.pipeline, textures=(tex_a, tex_b), samples_per_dispatch=per_dispatch(args.steps))
+        pmc_traffic.samples_per_dispatch = loop.samples_per_dispatch
 
         def set_partition(on):
             if world > 1 and tiles:
@@ -495,7 +518,7 @@ def main():
 
         # the same K steps the way the reference's frame loop issues them: one dispatch per sample
         single_ms = None
-        if loop.samples_per_dispatch > 1:
+        if loop.samples_per_dispatch > 1 and not os.environ.get("PTR_BENCH_SKIP_SINGLE"):   # (skipped under counter passes: every launch of a run should be of one size)
             keep = loop.samples_per_dispatch
             loop.samples_per_dispatch = 1
             single_elapsed, _ = timed(args.steps, multi)

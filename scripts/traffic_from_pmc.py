@@ -54,7 +54,7 @@ def main():
             kernels[name]["l1_hit_rate"] = 1.0 - l1_miss.get(name, 0.0) / l1_req[name]
         if name in wait and wave_cycles.get(name):
             kernels[name]["waves_waiting"] = wait[name] / wave_cycles[name]
-    doc = dict(workload=bench["config"]["workload"], kernels=kernels,
+    doc = dict(workload=bench["config"]["workload"], samples_per_dispatch=bench["config"].get("samples_per_dispatch", 1), kernels=kernels,
                note="per launch, mean over the launches of a short bench.py run under rocprofv3 --pmc (FETCH_SIZE and WRITE_SIZE in separate "
                     "passes); bytes = 2 x FETCH_SIZE (gfx950 tallies 128-byte requests as 64) + WRITE_SIZE; the doubling is an upper bound for "
                     "this kernel's scattered 64-byte reads; Infinity-Cache hits are included in FETCH_SIZE")
