@@ -13,6 +13,7 @@
 // merges the frame (bit-identical to one GPU).  samples: every rank renders spp / N whole frames of its own samples, one
 // all-reduce of the linearised images combines them.  Rank 0 writes the image.  --transport file stages the exchange through
 // files (several ranks on one GPU, for rehearsal); rccl uses the GPUs' xGMI links.
+#include <dirent.h>
 #include <sys/wait.h>
 #include <unistd.h>
 
@@ -68,6 +69,7 @@ scene_source load_source(const std::string& path, bool apply_transforms, bool in
 }
 // --gpus N without --rank: one child process per GPU (started before this process touches a GPU), the worst exit code wins.
 int launch_ranks(int argc, char** argv, uint32_t gpus, std::string rendezvous) {
+    const bool own_directory = rendezvous.empty();
     if (rendezvous.empty()) {
         char tmpl[] = "/tmp/ptr_headless_XXXXXX";
         if (!mkdtemp(tmpl)) { std::perror("mkdtemp"); return 2; }
@@ -94,6 +96,14 @@ int launch_ranks(int argc, char** argv, uint32_t gpus, std::string rendezvous) {
     for (pid_t pid : children) {
         int status = 0;
         if (waitpid(pid, &status, 0) < 0 || !WIFEXITED(status) || WEXITSTATUS(status) != 0) worst = WIFEXITED(status) && WEXITSTATUS(status) ? WEXITSTATUS(status) : 1;
+    }
+    if (own_directory) {   // the exchange's files (communicator id, staged chunks) go with the directory made for them
+        if (DIR* d = opendir(rendezvous.c_str())) {
+            while (const dirent* e = readdir(d))
+                if (std::strcmp(e->d_name, ".") != 0 && std::strcmp(e->d_name, "..") != 0) std::remove((rendezvous + "/" + e->d_name).c_str());
+            closedir(d);
+        }
+        rmdir(rendezvous.c_str());
     }
     return worst;
 }
