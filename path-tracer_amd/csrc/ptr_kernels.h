@@ -64,6 +64,9 @@ hipError_t launch_tonemap(hipStream_t s, const SceneMeta* meta, const ImageDesc*
 hipError_t launch_linearize_resolve(hipStream_t s, const ImageDesc* images, uint32_t output_index, uint32_t accumulation_index,
                                     uint32_t pixels, bool resolve);
 
+// Fills the 4 x 4-tiled copy of a row-major RGBA8 image (ceil(width / 4) * ceil(height / 4) * 64 bytes).
+hipError_t launch_tile_rgba8(hipStream_t s, const void* linear, void* tiled, uint32_t width, uint32_t height);
+
 // Tile-partition exchange: copies between the rows of an RGBA32F frame and the packed chunks an all-gather moves.
 // pack (unpack = false): ranks = 1, first_rank = the owner; unpack: first_rank = 0, ranks = world.
 hipError_t launch_stripes_copy(hipStream_t s, float4* image, uint32_t width, uint32_t height, uint32_t stripe_rows, uint32_t world,

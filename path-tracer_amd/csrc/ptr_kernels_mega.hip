@@ -148,6 +148,16 @@ hipError_t launch_linearize_resolve(hipStream_t s, const ImageDesc* images, uint
     return hipGetLastError();
 }
 
+// The tiled copy of an RGBA8 image (ImageDesc::tiled): texel (i, j) of the row-major image goes to tiled_texel(i, j).
+__global__ __launch_bounds__(256) void ptr_tile_rgba8(const uint32_t* linear, uint32_t* tiled, uint32_t width, uint32_t height) {
+    const uint32_t i = blockIdx.x * 16u + (threadIdx.x & 15u), j = blockIdx.y * 16u + (threadIdx.x >> 4);
+    if (i < width && j < height) tiled[tiled_texel((width + 3u) >> 2, (int32_t)i, (int32_t)j)] = linear[(size_t)j * width + i];
+}
+hipError_t launch_tile_rgba8(hipStream_t s, const void* linear, void* tiled, uint32_t width, uint32_t height) {
+    hipLaunchKernelGGL(ptr_tile_rgba8, dim3((width + 15u) / 16u, (height + 15u) / 16u), dim3(256), 0, s, (const uint32_t*)linear, (uint32_t*)tiled, width, height);
+    return hipGetLastError();
+}
+
 // Tile-partition exchange helpers (no counterpart in the single-GPU reference).  A frame of `height` rows is cut into
 // stripes of `stripe_rows` rows; rank r of `world` owns the stripes s with s % world == r.  pack: the owned stripes of one
 // rank, in order, as one contiguous chunk (`chunk_stripes` stripes, rows past the frame's end zero) -- what an all-gather

@@ -715,3 +715,22 @@ def test_several_samples_per_dispatch_with_the_partitions_and_where_it_is_refuse
         ctx.set_capture(None)
         cap.destroy()
     hip.FrameLoop(ctx, gs, 80, 72, "compute").frame(2)             # and fine again afterwards
+
+
+def test_texture_extents_that_are_no_multiple_of_the_tile(ctx):
+    """The shade step samples RGBA8 textures from a copy in 4 x 4 tiles; extents of 1, 3, 5, 10 ... texels leave partly
+    filled tiles at the right and bottom edges, and REPEAT addressing wraps from them to the first column and row."""
+    rng = np.random.default_rng(11)
+    for (aw, ah), (mw, mh) in (((10, 6), (5, 3)), ((1, 1), (2, 7)), ((13, 4), (4, 13))):
+        b = make_bundle("tiny", 0, 56, 36, max_bounce=4)
+        b = dict(b, textures=[None, rng.integers(0, 256, (ah, aw, 4), dtype=np.uint8), rng.integers(0, 256, (mh, mw, 4), dtype=np.uint8)])
+        for pipeline, use_flat in (("compute.wavefront", True), ("compute.megakernel", False)):
+            img, gs, _, _ = gpu_frames(ctx, b, 2, pipeline)
+            ref, _, _ = oracle_for(b, gs, 2, use_flat=use_flat)
+            assert_same(img, ref, f"{pipeline}, textures {aw}x{ah} and {mw}x{mh}")
+        again = rng.integers(0, 256, (ah, aw, 4), dtype=np.uint8)    # a second upload replaces the tiled copy too
+        gs.textures[1].update(again)
+        gs.texture_table[gs.textures[1].bindless_index] = again
+        img, _, _, _ = gpu_frames(ctx, b, 2, "compute.wavefront", gpu_scene=gs)
+        ref, _, _ = oracle_for(dict(b), gs, 2, use_flat=True)
+        assert_same(img, ref, "after a second upload")
