@@ -210,8 +210,9 @@ def make_parser():
     ap.add_argument("--partition", default="tiles", choices=["tiles", "samples"], help="how N > 1 GPUs share the work (see the module text)")
     ap.add_argument("--stripe-rows", type=int, default=8, help="tile partition: image rows per stripe (a multiple of 8)")
     ap.add_argument("--samples-per-dispatch", type=int, default=16,
-                    help="upper bound of the samples (= steps) one dispatch renders (\"dispatch.samples\"): the K steps are dealt evenly to "
-                         "ceil(K / this) dispatches; the image equals K single-sample dispatches bit for bit.  1 = the reference's one dispatch per sample")
+                    help="upper bound of the samples (= steps) one dispatch renders (\"dispatch.samples\"), times the number of GPUs in the tile "
+                         "partition (64 at most): the K steps are dealt evenly to as few dispatches as that allows; the image equals K "
+                         "single-sample dispatches bit for bit.  1 = the reference's one dispatch per sample")
     return ap
 
 
@@ -432,7 +433,8 @@ def main():
         by_handle = {tex_a.handle: img_a, tex_b.handle: img_b}
         # K steps in ceil(K / S) dispatches of (nearly) equal size
         def per_dispatch(steps):
-            limit = 1 if args.pipeline == "compute.megakernel" else max(1, min(16, args.samples_per_dispatch))
+            # a rank of N renders 1/N of every frame: N times the samples per dispatch keep its launches as full
+            limit = 1 if args.pipeline == "compute.megakernel" else max(1, min(64, args.samples_per_dispatch * (world if tiles else 1)))
             return max(1, -(-steps // -(-steps // limit)))
         loop = hip.FrameLoop(ctx, gpu, W, H, args.pipeline, textures=(tex_a, tex_b), samples_per_dispatch=per_dispatch(args.steps))
         pmc_traffic.samples_per_dispatch = loop.samples_per_dispatch

@@ -176,7 +176,7 @@ int ptr_set_sample_partition(ptr_ctx* ctx, uint32_t rank, uint32_t world);
  *                              ptr_buffer_write to them) the library checks on the GPU that every vertex id, material id,
  *                              node link and child reference stays inside the buffer it indexes, and fails the dispatch with
  *                              PTR_E_RANGE otherwise (one synchronisation per upload); 0: trust the caller.
- *      "dispatch.samples"      1 (default) .. 16: a "compute" dispatch of the wavefront pipeline renders that many consecutive
+ *      "dispatch.samples"      1 (default) .. 64: a "compute" dispatch of the wavefront pipeline renders that many consecutive
  *                              samples -- sample_index, sample_index + 1, ... of the metadata -- in one pass through the kernels
  *                              (every tile is queued that many times) and accumulates them in order; the output image then
  *                              holds what that many single-sample dispatches, with the caller's image swap after each

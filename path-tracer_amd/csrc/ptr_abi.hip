@@ -1279,7 +1279,7 @@ int ptr_set_option(ptr_ctx* c, const char* key, int value) {
         return PTR_OK;
     }
     if (!strcmp(key, "dispatch.samples")) {
-        if (value < 1 || value > 16) return fail(c, PTR_E_INVALID, "dispatch.samples: 1..16");
+        if (value < 1 || value > 64) return fail(c, PTR_E_INVALID, "dispatch.samples: 1..64");
         c->opt_dispatch_samples = value;
         return PTR_OK;
     }

@@ -5,7 +5,7 @@
 //   ptr_headless --scene file.{ptrscene,gltf,glb} [--apply-transforms | --instanced] [--gpu-bvh] [--copies NX NZ] --width W --height H --spp N [--max-bounce B] [--min-bounce B]
 //                [--dof 0|1] [--downscale D] [--debug-bvh 0|1] [--pipeline compute|compute.megakernel|compute.wavefront]
 //                [--pos x y z] [--target x y z] [--fov deg] [--aperture a] [--focus f] [--out image.pfm|image.ppm|image.png]
-//                [--samples-per-dispatch S]   (1..16: one dispatch renders S consecutive samples, same image, fewer launches)
+//                [--samples-per-dispatch S]   (1..64: one dispatch renders S consecutive samples, same image, fewer launches)
 //                [--gpus N [--partition tiles|samples] [--transport rccl|file] [--stripe-rows S] [--rendezvous DIR]]
 //
 // --gpus N (no counterpart in the single-device reference): the process starts N copies of itself, one per GPU, each with
@@ -196,7 +196,7 @@ int main(int argc, char** argv) {
         raytracing_pass->set_dispatch_size(width / 8 + 1, height / 8 + 1, 1);
 
         const auto t0 = std::chrono::steady_clock::now();
-        if (samples_per_dispatch == 0 || samples_per_dispatch > 16) throw std::runtime_error("--samples-per-dispatch: 1..16");
+        if (samples_per_dispatch == 0 || samples_per_dispatch > 64) throw std::runtime_error("--samples-per-dispatch: 1..64");
         for (uint32_t frame = 0; frame < frames;) {
             // one dispatch = the next `batch` samples, accumulated in order; the images swap once per dispatch
             const uint32_t batch = std::min(samples_per_dispatch, frames - frame);

@@ -1,0 +1,49 @@
+#!/usr/bin/env python3
+"""What one rank of an N-GPU tile partition costs, measured on ONE GPU (no exchange): K steps of the bench scene with
+ptr_set_partition(rank 0 of N), for several dispatch sizes.  T_1 / (N * T_N) of these figures is the scaling efficiency the
+render part alone allows; the all-gather and the barriers come on top.
+   python scripts/partition_probe.py --worlds 1 2 4 8 --steps 20"""
+import argparse
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "path-tracer_amd", "python"))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    import bench
+    ap = bench.make_parser()
+    ap.add_argument("--worlds", type=int, nargs="+", default=[1, 2, 4, 8])
+    ap.add_argument("--per-dispatch", type=int, nargs="+", default=[10, 16, 20])
+    ap.add_argument("--rounds", type=int, default=5)
+    args = ap.parse_args()
+    from path_tracer_amd import hip
+    sc, nodes, flat, meta, _ = bench.build_scene(args, 0)
+    ctx = hip.Context(0)
+    gpu = hip.GpuScene(ctx, sc, nodes, flat, meta)
+    base = {}
+    for per in args.per_dispatch:
+        for world in args.worlds:
+            ctx.set_partition(0, world, args.stripe_rows)
+            loop = hip.FrameLoop(ctx, gpu, args.width, args.height, args.pipeline, samples_per_dispatch=min(64, per))
+            loop.frames(2 * min(64, per)); ctx.sync()
+            best = 1e9
+            for _ in range(args.rounds):
+                loop.reset()
+                t0 = time.perf_counter()
+                loop.frames(args.steps)
+                ctx.sync()
+                best = min(best, time.perf_counter() - t0)
+            base.setdefault(per, best if world == 1 else None)
+            t1 = base[per] or best
+            print(f"samples per dispatch {min(64, per):2d}  world {world}: {best * 1e3:7.3f} ms for {args.steps} steps"
+                  f"   render-only efficiency {t1 / (world * best):.3f}", flush=True)
+    ctx.set_partition(0, 1, 8)
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()
