@@ -448,6 +448,8 @@ def main():
         ctx.set_option("frames.in_flight", args.frames_in_flight)
 
         exchange = ctx.create_compute_renderpass()
+        # the tile exchange needs the context on torch's stream (pack, all-gather and unpack are then one stream's work)
+        tile_exchange = ptdist.TileExchange(ctx, W, H, rank, world, args.stripe_rows) if (multi and tiles and args.stream == "torch") else None
 
         def order_streams():
             """With the context on its own stream the collectives (torch's current stream) and the kernels around them are
@@ -460,6 +462,9 @@ def main():
             """Closes the timed region with the exchange of the partition; returns the final image tensor.
             tiles: one all-gather of the owned stripes.  samples: linearize -> all-reduce -> resolve."""
             latest, scratch = loop.latest(), loop.output
+            if tiles and tile_exchange is not None:
+                tile_exchange.merge(latest)
+                return by_handle[latest.handle]
             if tiles:
                 order_streams()
                 return ptdist.gather_tiles(by_handle[latest.handle], rank, world, args.stripe_rows)

@@ -58,6 +58,40 @@ def gather_tiles(image, rank, world, stripe_rows, group=None):
     return merged[:H].contiguous()
 
 
+class _DeviceMemory:
+    """A library buffer seen through the CUDA array interface, so that torch can wrap it without a copy."""
+
+    def __init__(self, address, floats):
+        self.__cuda_array_interface__ = dict(shape=(floats,), typestr="<f4", data=(address, False), version=2)
+
+
+class TileExchange:
+    """The tile partition's exchange on the library's own kernels: ptr_image_pack_stripes -> ONE all-gather ->
+    ptr_image_unpack_stripes, in two device buffers made once (three launches and no temporary per exchange, where
+    gather_tiles builds the chunks with torch views and copies).  Everything runs on torch's current stream, which must be
+    the context's stream."""
+
+    def __init__(self, ctx, width, height, rank, world, stripe_rows):
+        self.ctx, self.rank, self.world, self.stripe_rows = ctx, rank, world, stripe_rows
+        stripes = (height + stripe_rows - 1) // stripe_rows
+        self.chunk_floats = ((stripes + world - 1) // world) * stripe_rows * width * 4
+        self.packed = ctx.create_buffer(self.chunk_floats * 4)
+        self.gathered = ctx.create_buffer(self.chunk_floats * 4 * world)
+        self.packed_t = torch.as_tensor(_DeviceMemory(self.packed.device_address, self.chunk_floats), device="cuda")
+        self.gathered_t = torch.as_tensor(_DeviceMemory(self.gathered.device_address, self.chunk_floats * world), device="cuda")
+
+    def merge(self, texture, group=None):
+        """All-gathers the stripes each rank owns of `texture` (an RGBA32F Texture of the context) into that same image."""
+        self.ctx.pack_stripes(texture, self.rank, self.world, self.stripe_rows, self.packed)
+        if dist.get_backend(group) == "gloo":                      # rehearsal path: stage through host memory
+            parts = [torch.empty(self.chunk_floats) for _ in range(self.world)]
+            dist.all_gather(parts, self.packed_t.cpu(), group=group)
+            self.gathered_t.copy_(torch.cat(parts))
+        else:
+            dist.all_gather_into_tensor(self.gathered_t, self.packed_t, group=group)
+        self.ctx.unpack_stripes(texture, self.world, self.stripe_rows, self.gathered)
+
+
 def allreduce_linear(image_linear, group=None):
     """Sums the linearized per-GPU means in place (alpha carries the number of contributions)."""
     if dist.is_initialized() and dist.get_world_size(group) > 1:

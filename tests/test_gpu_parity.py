@@ -734,3 +734,37 @@ def test_texture_extents_that_are_no_multiple_of_the_tile(ctx):
         img, _, _, _ = gpu_frames(ctx, b, 2, "compute.wavefront", gpu_scene=gs)
         ref, _, _ = oracle_for(dict(b), gs, 2, use_flat=True)
         assert_same(img, ref, "after a second upload")
+
+
+@pytest.mark.parametrize("width,height,world,stripe", [(40, 37, 3, 8), (17, 64, 4, 16), (8, 8, 2, 8), (33, 50, 8, 8)])
+def test_stripe_pack_and_unpack_kernels(ctx, width, height, world, stripe):
+    """ptr_image_pack_stripes / ptr_image_unpack_stripes against their definition: rank r's chunk holds the stripes r, r + world,
+    ... in order, zero-padded to ceil(stripes / world) stripes; unpacking the chunks of all ranks rebuilds the frame."""
+    from path_tracer_amd import hip
+    rng = np.random.default_rng(5)
+    frame = rng.random((height, width, 4), dtype=np.float32)
+    src = ctx.create_2d_texture(width, height, hip.FORMAT_RGBA32_SFLOAT); src.update(frame)
+    dst = ctx.create_2d_texture(width, height, hip.FORMAT_RGBA32_SFLOAT)
+    stripes = (height + stripe - 1) // stripe
+    chunk_stripes = (stripes + world - 1) // world
+    chunk_floats = chunk_stripes * stripe * width * 4
+    packed = ctx.create_buffer(chunk_floats * 4)
+    gathered = ctx.create_buffer(chunk_floats * 4 * world)
+    padded = np.zeros((chunk_stripes * world * stripe, width, 4), np.float32)
+    padded[:height] = frame
+    by_stripe = padded.reshape(chunk_stripes * world, stripe, width, 4)
+    for r in range(world):
+        ctx.pack_stripes(src, r, world, stripe, packed)
+        got = packed.read(np.float32).reshape(chunk_stripes, stripe, width, 4)
+        assert np.array_equal(got, by_stripe[r::world]), f"rank {r}"
+        gathered.write(got, r * chunk_floats * 4)
+    ctx.unpack_stripes(dst, world, stripe, gathered)
+    assert np.array_equal(dst.read(), frame)
+    small = ctx.create_buffer(16)
+    with pytest.raises(hip.HipError, match="needed"):
+        ctx.pack_stripes(src, 0, world, stripe, small)            # a buffer that cannot hold the chunk is refused
+    small.destroy()
+    for t in (src, dst):
+        t.destroy()
+    for b in (packed, gathered):
+        b.destroy()
