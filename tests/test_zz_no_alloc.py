@@ -9,14 +9,14 @@ from common import make_bundle, oracle_frames
 pytestmark = pytest.mark.gpu
 
 
-def render(ctx, gs, width, height, spp, static, pipeline="compute"):
+def render(ctx, gs, width, height, spp, static, pipeline="compute", per_dispatch=1):
     """`spp` frames of the reference's frame protocol (src/main.cpp:406-416) through one of the two entry points."""
     from path_tracer_amd import hip
     loop = hip.FrameLoop(ctx, gs, width, height, pipeline)
     if static:
         loop.renderpass.execute = lambda: ctx.dispatch_static(pipeline, loop.renderpass.constants, *loop.renderpass.group_count)
-    for _ in range(spp):
-        loop.frame()
+    loop.samples_per_dispatch = per_dispatch
+    loop.frames(spp)
     return loop.latest().read()
 
 
@@ -49,6 +49,9 @@ def test_static_dispatch_equals_the_allocating_dispatch_twice_in_a_row_the_secon
         # the strict drop-in kernel needs no scratch at all; the static entry point launches it too
         mega = render(ctx, gs_small, 56, 40, 2, static=False, pipeline="compute.megakernel")
         assert np.array_equal(render(ctx, gs_small, 56, 40, 2, static=True, pipeline="compute.megakernel"), mega)
+
+        # several samples per dispatch ("dispatch.samples") through the fixed scratch: 3 x 2 samples of the small scene
+        assert np.array_equal(render(ctx, gs_small, 56, 40, 6, static=True, per_dispatch=2), render(ctx, gs_small, 56, 40, 6, static=False))
 
         # back and forth between the two entry points on one context: neither disturbs the other
         assert np.array_equal(render(ctx, gs_big, 200, 120, 2, static=False), render(ctx, gs_big, 200, 120, 2, static=True))
