@@ -486,19 +486,22 @@ static void flat_walk(const void* blob, int32_t root, v3 o, v3 d, float min_t, i
                 const float t1 = fmin_(min3_(fx, fy, fz), s->best_t);
                 if (t1 * FLAT_PAD >= t0) key[k] = t0;
             }
-            /* sorting network (0,1)(2,3)(0,2)(1,3)(1,2): nearest entry first; misses (+inf) sink to the end */
-            static const int net[5][2] = { { 0, 1 }, { 2, 3 }, { 0, 2 }, { 1, 3 }, { 1, 2 } };
-            for (int st = 0; st < 5; st++) {
+            /* three compare-exchanges (0,1)(2,3)(0,2): the nearest entry comes to slot 0, the farther of the two pair
+             * winners -- most often the second nearest -- to slot 2, and slots 1 and 3 keep the loser of each pair.  (The
+             * kernels' order; a full sort would save under 1 % of the node visits.  Misses carry +inf.) */
+            static const int net[3][2] = { { 0, 1 }, { 2, 3 }, { 0, 2 } };
+            for (int st = 0; st < 3; st++) {
                 const int a = net[st][0], b = net[st][1];
                 if (key[a] > key[b]) {
                     float tk = key[a]; key[a] = key[b]; key[b] = tk;
                     int32_t tr = ref[a]; ref[a] = ref[b]; ref[b] = tr;
                 }
             }
-            int n = 0;
-            for (int k = 0; k < 4; k++) n += key[k] < inf;
-            if (n > 0) {
-                for (int k = n - 1; k >= 1; k--) stack[sp++] = ref[k];  /* farthest first, so the nearer pops first */
+            if (key[0] < inf) {
+                /* the others that were hit go on the stack: slot 3, slot 1, then slot 2 on top */
+                if (key[3] < inf) stack[sp++] = ref[3];
+                if (key[1] < inf) stack[sp++] = ref[1];
+                if (key[2] < inf) stack[sp++] = ref[2];
                 cur = ref[0];
                 continue;
             }
