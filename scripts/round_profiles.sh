@@ -10,6 +10,7 @@ mkdir -p "$OUT"
 # PTR_BENCH_SKIP_SINGLE: without the one-sample-per-dispatch leg every launch of a kernel in this run has the size of the timed
 # region's launches, so the average duration rocprofv3 reports is comparable with roofline.avg_launch_ms / solo.avg_launch_ms
 PTR_BENCH_SKIP_SINGLE=1 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o s -- python3 bench.py --steps 20 --warmup 5 --cpu-seconds 0 > "$OUT/bench_under_rocprof.json" 2> "$OUT/bench_under_rocprof.err"
+python3 scripts/phase_averages.py "$OUT/stats/s_kernel_trace.csv" "$OUT/bench_under_rocprof.json" > "$OUT/extend_launches.txt"
 echo "kernel stats done"
 PMC_TARGET=bench scripts/pmc_passes.sh "$OUT/pmc"
 python3 scripts/pmc_summary.py "$OUT/pmc" > "$OUT/pmc_summary.txt"
