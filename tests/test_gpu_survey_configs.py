@@ -6,8 +6,10 @@ that traces ~0.5 Mrays/s allow:
       (stronger than the RMSE bound the contract asks for);
   headline  the benchmark's own scene at the benchmark's own size, against the oracle on row bands, bit for bit;
   C1  atrium 1280x720, max_bounce 4: both pipelines against the oracle on row bands;
-  C4  street exterior 3840x2160 in tile mode over 4 ranks: the union of the ranks' stripes is bit-identical to the
-      single-GPU frame (the ranks are four partitions of one context here; the all-gather is tested on CPU)."""
+  C4  street exterior (2.8 M triangles) 3840x2160, 64 samples, tile mode over 8 ranks: the ranks' stripes, packed and
+      unpacked by the library's stripe kernels, rebuild the single-GPU frame bit for bit (the ranks are eight partitions of
+      one context here; the collective runs in the multi-process tests);
+  C5  100.7 M triangles as placed copies, one rank of eight of the sample partition against the oracle."""
 import numpy as np
 import pytest
 
@@ -112,22 +114,58 @@ def test_c3_street_interior_1080p_sampled_bands(ctx):
     assert np.isfinite(img).all() and img[..., :3].min() >= 0.0 and img[..., :3].max() <= 1.0 and (img[..., 3] == 1.0).all()
 
 
-def test_c4_street_exterior_4k_tile_mode(ctx):
-    W, H, world, spp = 3840, 2160, 4, 2
-    b = make_bundle("street_exterior", 400_000, W, H, max_bounce=4)
-    whole, gs, _, _ = gpu_frames(ctx, b, spp, "compute.wavefront")
-    stripe_of_row = (np.arange(H) // 8) % world
-    merged = np.zeros_like(whole)
+def test_c4_street_exterior_4k_64spp_tile_mode_over_eight_ranks(ctx):
+    """C4 at its size: the benchmark's 2.8 M-triangle street, 3840x2160, 64 samples (dispatches of 16), tiles over 8 ranks.
+    One GPU plays the ranks one after the other; every rank's stripes are packed by ptr_image_pack_stripes, the chunks are
+    laid side by side the way an all-gather delivers them, and ptr_image_unpack_stripes rebuilds the frame: bit-identical to
+    the frame one GPU renders alone, which in turn equals the oracle on row bands.  (The collective itself runs in the
+    multi-process tests; on the wire it moves exactly these chunks.)"""
+    import os
+    import sys
+    from path_tracer_amd import hip
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    W, H, world, spp, per_dispatch, stripe = 3840, 2160, 8, 64, 16, 8
+    args = bench.make_parser().parse_args(["--width", str(W), "--height", str(H)])
+    sc, nodes, flat, meta, _ = bench.build_scene(args, rank=1)
+    assert sc["triangles"].shape[0] == 2_796_540
+    b = dict(sc, nodes=nodes, flat=flat, meta=meta, width=W, height=H)
+    gs = hip.GpuScene(ctx, b, nodes, flat, meta)
+    loop = hip.FrameLoop(ctx, gs, W, H, "compute", samples_per_dispatch=per_dispatch)
+
+    def render():
+        loop.reset()
+        for t in (loop.accumulation, loop.output):
+            t.update(np.zeros((H, W, 4), np.float32))
+        loop.frames(spp)
+        return loop.latest()
+
+    whole = render().read()
+    bands = [(0, 2), (1079, 1081), (2158, 2160)]
+    assert_bands_equal(whole, oracle_bands(b, gs, bands, spp), bands, "C4, one GPU, 64 samples")
+
+    chunk_bytes = -(-((H + stripe - 1) // stripe) // world) * stripe * W * 16
+    packed = ctx.create_buffer(chunk_bytes)
+    gathered = ctx.create_buffer(chunk_bytes * world)
+    merged = ctx.create_2d_texture(W, H, hip.FORMAT_RGBA32_SFLOAT)
+    stripe_of_row = (np.arange(H) // stripe) % world
     try:
         for rank in range(world):
-            ctx.set_partition(rank, world, 8)
-            part, _, _, _ = gpu_frames(ctx, b, spp, "compute.wavefront", gpu_scene=gs)
-            mine = stripe_of_row == rank
-            assert (part[~mine] == 0).all()                      # a rank never writes foreign rows
-            merged[mine] = part[mine]
+            ctx.set_partition(rank, world, stripe)
+            latest = render()
+            if rank == 3:
+                part = latest.read()
+                assert (part[stripe_of_row != rank] == 0).all()   # a rank never writes foreign rows
+            ctx.pack_stripes(latest, rank, world, stripe, packed)
+            gathered.write(packed.read(np.uint8), rank * chunk_bytes)
     finally:
-        ctx.set_partition(0, 1, 8)
-    assert np.array_equal(merged, whole)
+        ctx.set_partition(0, 1, stripe)
+    ctx.unpack_stripes(merged, world, stripe, gathered)
+    assert np.array_equal(merged.read(), whole)
+    for t in (merged, loop.accumulation, loop.output):
+        t.destroy()
+    for buf in (packed, gathered):
+        buf.destroy()
 
 
 def test_c5_100m_triangles_as_36_placed_copies_one_rank_of_eight(ctx):
