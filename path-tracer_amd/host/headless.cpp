@@ -109,6 +109,17 @@ int launch_ranks(int argc, char** argv, uint32_t gpus, std::string rendezvous) {
 }
 }  // namespace
 
+const char kUsage[] =
+    "usage: ptr_headless --scene file.{ptrscene,gltf,glb} [options]\n"
+    "  scene     --apply-transforms | --instanced (glTF node transforms: applied to the geometry | kept as placed copies)\n"
+    "            --copies NX NZ (the scene placed on a grid through a top-level tree)   --gpu-bvh (tree built on the GPU)\n"
+    "  frame     --width W --height H --spp N --max-bounce N --min-bounce N --downscale N --dof 0|1 --debug-bvh 0|1\n"
+    "            --samples-per-dispatch N (1..64 samples per dispatch; same image)   --pipeline compute|compute.megakernel|compute.wavefront\n"
+    "  camera    --pos X Y Z --target X Y Z --fov DEGREES --aperture A --focus DISTANCE\n"
+    "  output    --out file.ppm | file.png (8 bits per channel, 256 * clamp(c, 0, 0.999)) | any other name (\"PTRF w h\\n\" + the float RGBA image)\n"
+    "  GPUs      --gpus N (one process per GPU is started)   --partition tiles|samples   --stripe-rows N (a multiple of 8)\n"
+    "            --transport rccl|file   --rendezvous DIR   [--rank R --device D: set for the started processes]\n";
+
 int main(int argc, char** argv) {
     std::string scene_path, out_path, pipeline = "compute";
     bool apply_transforms = false, gpu_bvh = false, instanced = false;
@@ -151,9 +162,10 @@ int main(int argc, char** argv) {
         else if (is("--focus")) focus = (float)std::atof(next());
         else if (is("--pos")) { for (float& c : pos) c = (float)std::atof(next()); }
         else if (is("--target")) { for (float& c : target) c = (float)std::atof(next()); }
-        else { std::fprintf(stderr, "unknown argument %s\n", argv[i]); return 2; }
+        else if (is("--help") || is("-h")) { std::fputs(kUsage, stdout); return 0; }
+        else { std::fprintf(stderr, "unknown argument %s\n%s", argv[i], kUsage); return 2; }
     }
-    if (scene_path.empty()) { std::fprintf(stderr, "usage: ptr_headless --scene file.{ptrscene,gltf,glb} [options]\n"); return 2; }
+    if (scene_path.empty()) { std::fputs(kUsage, stderr); return 2; }
 
     if (gpus == 0 || (partition != "tiles" && partition != "samples")) { std::fprintf(stderr, "--gpus N >= 1, --partition tiles|samples\n"); return 2; }
     if (gpus > 1 && rank < 0) return launch_ranks(argc, argv, gpus, rendezvous);
