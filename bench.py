@@ -502,6 +502,7 @@ def main():
             barrier()
             t0 = time.perf_counter()
             loop.frames(steps)
+            ctx.flush()    # dispatches held back under "dispatch.coalesce" are enqueued now (nothing to do otherwise)
             final = combine() if with_exchange else by_handle[loop.latest().handle]
             torch.cuda.synchronize()
             if multi:
@@ -523,6 +524,7 @@ def main():
         ctx.profile_enable(False)
         prof = ctx.profile_read(reset=True)
         ctx.set_option("profile.extend_only", 0)
+        final = final.clone()    # the legs below render into the same two images
         timed_image = final.cpu().numpy() if (rank == 0 and (tiles or world == 1)) else None
 
         # what a caller pays on top when it reads every finished frame back over PCIe (33 MB at 1080p)
@@ -537,11 +539,17 @@ def main():
             keep = loop.samples_per_dispatch
             loop.samples_per_dispatch = 1
             single_elapsed, _ = timed(args.steps, multi)
+            # ... and the same K single-sample dispatches with the library holding them back and rendering `keep` at a time
+            ctx.set_option("dispatch.coalesce", keep)
+            coalesced_elapsed, coalesced_final = timed(args.steps, multi)
+            ctx.set_option("dispatch.coalesce", 1)
+            coalesced_equal = bool(torch.equal(coalesced_final, final)) if (tiles or world == 1) else None
             loop.samples_per_dispatch = keep
-            t_single = torch.tensor([single_elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+            t_single = torch.tensor([single_elapsed, coalesced_elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
             if multi:
                 dist.all_reduce(t_single, op=dist.ReduceOp.MAX)
-            single_ms = float(t_single.item()) / args.steps * 1e3
+            single_ms = float(t_single[0].item()) / args.steps * 1e3
+            coalesced_ms = float(t_single[1].item()) / args.steps * 1e3
 
         # strong scaling needs the one-GPU time of the SAME total work on the same hardware: every rank renders the whole
         # frames alone (no partition, no exchange), outside the timed region
@@ -587,7 +595,10 @@ def main():
             line["config"]["warmup_steps_run"] = warmup_steps
             if single_ms is not None:
                 line["one_sample_per_dispatch"] = {"ms_per_step": single_ms, "value": rays_total / (single_ms * 1e-3 * args.steps) / 1e6, "unit": "Mrays/s",
-                                                    "note": "the same K steps as K dispatches of one sample each (the reference's frame protocol), same partition and exchange, outside the timed region"}
+                                                    "note": "the same K steps as K dispatches of one sample each (the reference's frame protocol), same partition and exchange, outside the timed region",
+                                                    "coalesced": {"ms_per_step": coalesced_ms, "value": rays_total / (coalesced_ms * 1e-3 * args.steps) / 1e6, "unit": "Mrays/s",
+                                                                  "dispatch.coalesce": loop.samples_per_dispatch, "image_equals_timed_region": coalesced_equal,
+                                                                  "note": "the same K single-sample dispatches with \"dispatch.coalesce\" set: the library holds them back and renders them as batched dispatches"}}
             if timed_image is not None and args.pipeline != "compute.megakernel" and flat is not None and args.cpu_seconds > 0:
                 line["parity_check"] = parity_check(sc, nodes, flat, meta, gpu, timed_image, args.steps)
                 log(rank, "parity_check:", line["parity_check"])

@@ -47,6 +47,11 @@ const char* ptr_last_error(const ptr_ctx* ctx);
 /* Blocks until everything enqueued on the context's stream has finished (vkrenderer::begin_frame's
  * fence wait, src/vk-renderer.cpp:214-221). */
 int ptr_sync(ptr_ctx* ctx);
+/* Enqueues the "compute" dispatches the context is holding back ("dispatch.coalesce" below) without waiting for them: for
+ * callers that go on to use the images on the same stream by means of their own (a wrapped image, a device pointer).  Every
+ * other entry point that reads or changes what a dispatch sees does the same on its own.  No counterpart in the reference,
+ * whose dispatches are recorded into the frame's command buffer as they come (src/compute-renderpass.cpp:51-56). */
+int ptr_flush(ptr_ctx* ctx);
 
 /* ---- buffers: vkrenderer::create_buffer + Buffer::write (src/vk-renderer.cpp:140-142,248-261) and the
  *      device address the renderpass pushes (src/compute-renderpass.cpp:46-49) ---- */
@@ -188,6 +193,20 @@ int ptr_set_sample_partition(ptr_ctx* ctx, uint32_t rank, uint32_t world);
  *                              tile partition still has a full GPU's worth of rays.  Needs output and accumulation images of
  *                              the same extent; not available with ptr_set_capture, the megakernel or debug_bvh
  *                              (PTR_E_UNSUPPORTED / PTR_E_STATE).
+ *      "dispatch.coalesce"     1 (default) .. 64: the reference's frame loop as it is -- write sample_index, dispatch, swap the
+ *                              two images, once per sample (src/main.cpp:406-416) -- at the speed of "dispatch.samples": the
+ *                              context holds back up to that many consecutive "compute" dispatches that continue one
+ *                              accumulation chain (same constants and metadata except sample_index + 1 and the two image
+ *                              indices swapped) and renders them as ONE dispatch of that many samples.  It runs when the
+ *                              count is reached, when a dispatch does not continue the chain, and before any other call that
+ *                              reads or changes what it sees (ptr_sync, ptr_flush, image and buffer reads, uploads, writes to
+ *                              a buffer it reads, options, partitions, destruction; NOT a write to the metadata buffer, whose
+ *                              contents a dispatch takes when it is issued).  Both images then hold exactly what the single
+ *                              dispatches would have left: the last result, and the one before it.  What differs: a
+ *                              dispatch that is held back has not been enqueued when ptr_dispatch returns (use ptr_flush
+ *                              before touching the images by other means), and an error it runs into is reported by the
+ *                              call that runs it.  Only for dispatches "dispatch.samples" could render (wavefront pipeline,
+ *                              no capture, no counting run, no debug_bvh); all others run at once, after the ones held back.
  *      "shade.pregather"       1 (default): the wavefront shade step reads one 80-byte record per hit triangle (vertex
  *                              normals, uvs, material id, geometry normal) that the library gathers once from the index /
  *                              positions / normals / uvs buffers of the dispatch and re-gathers after any ptr_buffer_write

@@ -103,6 +103,18 @@ struct ptr_ctx {
     int opt_index_words = 3;        // layout of the index buffer: 3 = the reference's packed words, 4 = v0, v1, v2, material
     int opt_dispatch_samples = 1;   // samples one "compute" dispatch of the wavefront pipeline renders (sample_index, +1, ...)
     int opt_shade_pregather = 1;    // wavefront shade reads per-triangle records gathered once per scene
+    // "dispatch.coalesce": consecutive single-sample "compute" dispatches that continue one accumulation chain (same scene,
+    // sample_index + 1, the two images swapped) are held back and rendered as ONE dispatch of that many samples
+    int opt_coalesce = 1;           // dispatches held back at most (1 = every dispatch runs at once)
+    struct Pending {
+        bool active = false;
+        uint8_t last[64] = {};      // constant block of the newest dispatch held back
+        ptr::SceneMeta meta{};      // metadata of the first one (the others differ in sample_index only)
+        uint32_t count = 0, gx = 0, gy = 0;
+        int force = 0;
+        ptr_handle reads[9] = {};   // buffers the held-back dispatches will read (a write to one of them runs them first)
+    };
+    Pending pending;
     // the records, and what they were built from: addresses + write generations of indices / positions / normals / uvs
     void* shade_records = nullptr;
     size_t shade_records_bytes = 0;
@@ -182,6 +194,12 @@ hipError_t static_scratch_address(int device, uint32_t** out) {
 int bind_device(ptr_ctx* c) {
     PTR_HIP_CHECK(c, hipSetDevice(c->device));
     return PTR_OK;
+}
+// Every entry point that looks at or changes what a dispatch sees starts here: held-back dispatches run first.
+int flush_pending(ptr_ctx* c);
+int enter(ptr_ctx* c) {
+    int rc = bind_device(c);
+    return rc ? rc : flush_pending(c);
 }
 
 BufferRec* find_buffer(ptr_ctx* c, ptr_handle h) {
@@ -480,11 +498,15 @@ int validate_scene(ptr_ctx* c, const uint64_t addr[7], const ptr_handle handles[
 
 // no_alloc: the ptr_dispatch_static variant -- the frame runs start to end on the context's stream in this GPU's fixed
 // scratch array, and nothing on the way allocates (no scene check, no record gathering, no streams or events).
-int dispatch_compute(ptr_ctx* c, const uint8_t constants[64], uint32_t gx, uint32_t gy, int force /*0 auto,1 mega,2 wavefront*/, bool no_alloc = false) {
+// batch: dispatches that were held back ("dispatch.coalesce"), rendered now as one dispatch of batch->count samples; the
+// constants are the newest one's, the metadata the first one's.
+int dispatch_compute(ptr_ctx* c, const uint8_t constants[64], uint32_t gx, uint32_t gy, int force /*0 auto,1 mega,2 wavefront*/, bool no_alloc = false,
+                     const ptr_ctx::Pending* batch = nullptr) {
     const ParsedConstants k = parse_constants(constants);
     ptr::SceneMeta meta;
-    int rc = read_meta(c, k.addr[0], &meta);
-    if (rc) return rc;
+    int rc = PTR_OK;
+    if (batch) meta = batch->meta;
+    else if ((rc = read_meta(c, k.addr[0], &meta))) return rc;
     if (meta.width == 0 || meta.height == 0) return fail(c, PTR_E_STATE, "scene metadata: zero width/height");
     if (meta.downscale_factor < 1) return fail(c, PTR_E_STATE, "scene metadata: downscale_factor < 1");
     if (meta.sample_index == 0) return fail(c, PTR_E_STATE, "scene metadata: sample_index must start at 1 (1/sample_index weights the frame)");
@@ -525,6 +547,14 @@ int dispatch_compute(ptr_ctx* c, const uint8_t constants[64], uint32_t gx, uint3
     }
     sv.stats = c->stats_on ? c->d_stats : nullptr;
     sv.batch_samples = (uint32_t)c->opt_dispatch_samples;
+    if (batch) {
+        // dispatch i read the image dispatch i - 1 wrote: the chain starts from the first one's accumulation image -- the newest
+        // one's accumulation image for an odd count, its output image for an even one -- and ends in the newest one's output
+        // image; the newest one's accumulation image is left as the dispatch before it wrote it
+        sv.batch_samples = batch->count;
+        sv.accumulation_index = (batch->count & 1u) ? k.accumulation_index : k.output_index;
+        sv.prev_image_plus_one = batch->count >= 2u ? k.accumulation_index + 1u : 0u;
+    }
 
     BufferRec* bvh_buf = &c->buffers[handles[1]];
     BufferRec* flat_buf = bvh_buf->flat ? find_buffer(c, bvh_buf->flat) : nullptr;
@@ -720,6 +750,60 @@ int dispatch_compute(ptr_ctx* c, const uint8_t constants[64], uint32_t gx, uint3
     return PTR_OK;
 }
 
+int flush_pending(ptr_ctx* c) {
+    if (!c->pending.active) return PTR_OK;
+    const ptr_ctx::Pending p = c->pending;
+    c->pending.active = false;
+    return dispatch_compute(c, p.last, p.gx, p.gy, p.force, false, &p);
+}
+
+// A "compute" dispatch under "dispatch.coalesce" > 1: held back when it starts or continues an accumulation chain the batched
+// dispatch can render (wavefront pipeline, one sample, no counting or capture run), otherwise run at once -- after the ones
+// held back.  A dispatch that is held back reports nothing yet: what it would have reported comes from the call that runs it.
+int dispatch_or_hold(ptr_ctx* c, const uint8_t constants[64], uint32_t gx, uint32_t gy, int force) {
+    int rc = PTR_OK;
+    const ParsedConstants k = parse_constants(constants);
+    ptr::SceneMeta meta;
+    ptr_handle handles[7] = {};
+    bool can = c->opt_coalesce > 1 && c->opt_dispatch_samples == 1 && !c->stats_on && !c->capture && force != 1 &&
+               read_meta(c, k.addr[0], &meta) == PTR_OK && meta.debug_bvh != 1u && meta.sample_index != 0u;
+    for (int i = 0; can && i < 7; i++) can = buffer_at(c, k.addr[i], 1, &handles[i]) != nullptr;
+    if (can && force == 0 && !c->buffers[handles[1]].flat) can = false;   // no flattened layout bound: the megakernel's frame
+    // a dispatch that names no usable image fails now, not when it would have run
+    if (can && (check_storage_image(c, k.output_index, "output") || check_storage_image(c, k.accumulation_index, "accumulation"))) can = false;
+    if (!can) {
+        if ((rc = flush_pending(c))) return rc;
+        return dispatch_compute(c, constants, gx, gy, force);
+    }
+    ptr_ctx::Pending& p = c->pending;
+    if (p.active) {
+        const ParsedConstants last = parse_constants(p.last);
+        ptr::SceneMeta expect = p.meta;
+        expect.sample_index = p.meta.sample_index + p.count;
+        const bool next = p.gx == gx && p.gy == gy && p.force == force && p.meta.sample_index <= 0xffffffffu - p.count &&
+                          !memcmp(&meta, &expect, sizeof meta) && !memcmp(constants, p.last, 56) &&
+                          k.output_index == last.accumulation_index && k.accumulation_index == last.output_index;
+        if (next) {
+            memcpy(p.last, constants, 64);
+            p.count++;
+        } else if ((rc = flush_pending(c))) {
+            return rc;
+        }
+    }
+    if (!p.active) {
+        p.active = true;
+        memcpy(p.last, constants, 64);
+        p.meta = meta;
+        p.count = 1; p.gx = gx; p.gy = gy; p.force = force;
+        for (int i = 0; i < 7; i++) p.reads[i] = i == 0 ? 0 : handles[i];   // the metadata was taken by value
+        p.reads[7] = c->buffers[handles[1]].flat;
+        const BufferRec* flat = find_buffer(c, p.reads[7]);
+        p.reads[8] = flat ? flat->instances : 0;
+    }
+    if (p.count >= (uint32_t)c->opt_coalesce) return flush_pending(c);
+    return PTR_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -776,6 +860,7 @@ int ptr_ctx_create(int device, ptr_ctx** out) {
 int ptr_ctx_destroy(ptr_ctx* c) {
     if (!c) return PTR_E_INVALID;
     (void)hipSetDevice(c->device);
+    (void)flush_pending(c);   // dispatches still held back write their images like any other
     for (auto& slot : c->slots) if (slot.stream) (void)hipStreamSynchronize(slot.stream);
     (void)hipStreamSynchronize(c->stream);
     drain_profile(c);
@@ -802,7 +887,7 @@ int ptr_ctx_destroy(ptr_ctx* c) {
 
 int ptr_ctx_set_stream(ptr_ctx* c, void* hip_stream) {
     if (!c) return PTR_E_INVALID;
-    int rc = bind_device(c); if (rc) return rc;
+    int rc = enter(c); if (rc) return rc;
     if ((rc = drain_frames(c))) return rc;
     PTR_HIP_CHECK(c, hipStreamSynchronize(c->stream));
     for (auto& slot : c->slots) slot.in_flight = false;  // their `consumed` events belong to the old stream, which is idle now
@@ -821,9 +906,14 @@ int ptr_ctx_set_stream(ptr_ctx* c, void* hip_stream) {
 
 const char* ptr_last_error(const ptr_ctx* c) { return c ? c->error.c_str() : g_create_error.c_str(); }
 
+int ptr_flush(ptr_ctx* c) {
+    if (!c) return PTR_E_INVALID;
+    return enter(c);
+}
+
 int ptr_sync(ptr_ctx* c) {
     if (!c) return PTR_E_INVALID;
-    int rc = bind_device(c); if (rc) return rc;
+    int rc = enter(c); if (rc) return rc;
     if ((rc = drain_frames(c))) return rc;
     PTR_HIP_CHECK(c, hipStreamSynchronize(c->stream));
     // whatever the caller wrote into device memory by other means before this point is ordered before later frames
@@ -834,7 +924,7 @@ int ptr_sync(ptr_ctx* c) {
 int ptr_buffer_create(ptr_ctx* c, size_t size, ptr_handle* out) {
     if (!c || !out) return PTR_E_INVALID;
     if (size == 0) return fail(c, PTR_E_INVALID, "ptr_buffer_create: size 0");
-    int rc = bind_device(c); if (rc) return rc;
+    int rc = enter(c); if (rc) return rc;
     BufferRec b;
     PTR_HIP_CHECK(c, hipMalloc(&b.ptr, size));
     b.size = size; b.alive = true;
@@ -850,7 +940,7 @@ int ptr_buffer_destroy(ptr_ctx* c, ptr_handle h) {
     if (!c) return PTR_E_INVALID;
     BufferRec* b = find_buffer(c, h);
     if (!b) return fail(c, PTR_E_INVALID, "ptr_buffer_destroy: unknown buffer %u", h);
-    int rc = bind_device(c); if (rc) return rc;
+    int rc = enter(c); if (rc) return rc;
     if ((rc = drain_frames(c))) return rc;
     PTR_HIP_CHECK(c, hipStreamSynchronize(c->stream));
     PTR_HIP_CHECK(c, hipFree(b->ptr));
@@ -868,6 +958,10 @@ int ptr_buffer_write(ptr_ctx* c, ptr_handle h, const void* data, size_t offset, 
     if (offset > b->size || size > b->size - offset) return fail(c, PTR_E_RANGE, "ptr_buffer_write: [%zu, +%zu) outside a %zu-byte buffer", offset, size, b->size);
     if (size == 0) return PTR_OK;
     int rc = bind_device(c); if (rc) return rc;
+    // dispatches held back read their metadata when they were issued: the per-frame metadata write does not disturb them
+    if (c->pending.active)
+        for (ptr_handle r : c->pending.reads)
+            if (r == h) { if ((rc = flush_pending(c))) return rc; break; }
     if (frame_reads(c, h) && (rc = drain_frames(c))) return rc;  // a frame in flight still reads this buffer
     if (!b->shadow.empty()) memcpy(b->shadow.data() + offset, data, size);
     b->flat_view_valid = false;
@@ -896,7 +990,7 @@ int ptr_buffer_read(ptr_ctx* c, ptr_handle h, void* dst, size_t offset, size_t s
     if (!dst && size) return fail(c, PTR_E_INVALID, "ptr_buffer_read: null dst");
     if (offset > b->size || size > b->size - offset) return fail(c, PTR_E_RANGE, "ptr_buffer_read: [%zu, +%zu) outside a %zu-byte buffer", offset, size, b->size);
     if (size == 0) return PTR_OK;
-    int rc = bind_device(c); if (rc) return rc;
+    int rc = enter(c); if (rc) return rc;
     PTR_HIP_CHECK(c, hipMemcpyAsync(dst, (const uint8_t*)b->ptr + offset, size, hipMemcpyDeviceToHost, c->stream));
     PTR_HIP_CHECK(c, hipStreamSynchronize(c->stream));
     return PTR_OK;
@@ -934,7 +1028,7 @@ int ptr_image_create(ptr_ctx* c, uint32_t w, uint32_t h, int format, ptr_handle 
     if (ts == 0) return fail(c, PTR_E_UNSUPPORTED, "ptr_image_create: format %d (RGBA8_UNORM and RGBA32_SFLOAT are implemented)", format);
     if (w == 0 || h == 0) return fail(c, PTR_E_INVALID, "ptr_image_create: zero extent");
     if (sampler != 0 && (sampler >= c->samplers.size() || !c->samplers[sampler].alive)) return fail(c, PTR_E_INVALID, "ptr_image_create: unknown sampler %u", sampler);
-    int rc = bind_device(c); if (rc) return rc;
+    int rc = enter(c); if (rc) return rc;
     void* mem = nullptr;
     PTR_HIP_CHECK(c, hipMalloc(&mem, (size_t)w * h * ts));
     PTR_HIP_CHECK(c, hipMemsetAsync(mem, 0, (size_t)w * h * ts, c->stream));
@@ -955,7 +1049,7 @@ int ptr_image_wrap(ptr_ctx* c, void* device_memory, uint32_t w, uint32_t h, int 
     if (texel_size(format) == 0) return fail(c, PTR_E_UNSUPPORTED, "ptr_image_wrap: format %d", format);
     if (!device_memory || ((uintptr_t)device_memory & 15u)) return fail(c, PTR_E_INVALID, "ptr_image_wrap: memory must be non-null and 16-byte aligned");
     if (w == 0 || h == 0) return fail(c, PTR_E_INVALID, "ptr_image_wrap: zero extent");
-    int rc = bind_device(c); if (rc) return rc;
+    int rc = enter(c); if (rc) return rc;
     return new_image(c, device_memory, false, w, h, format, 0, out);
 }
 
@@ -963,7 +1057,7 @@ int ptr_image_destroy(ptr_ctx* c, ptr_handle h) {
     if (!c) return PTR_E_INVALID;
     ImageRec* im = find_image(c, h);
     if (!im) return fail(c, PTR_E_INVALID, "ptr_image_destroy: unknown image %u", h);
-    int rc = bind_device(c); if (rc) return rc;
+    int rc = enter(c); if (rc) return rc;
     if ((rc = drain_frames(c))) return rc;
     PTR_HIP_CHECK(c, hipStreamSynchronize(c->stream));
     if (im->owned) PTR_HIP_CHECK(c, hipFree(im->ptr));
@@ -977,7 +1071,7 @@ int ptr_image_upload(ptr_ctx* c, ptr_handle h, const void* texels) {
     ImageRec* im = find_image(c, h);
     if (!im) return fail(c, PTR_E_INVALID, "ptr_image_upload: unknown image %u", h);
     if (!texels) return fail(c, PTR_E_INVALID, "ptr_image_upload: null texels");
-    int rc = bind_device(c); if (rc) return rc;
+    int rc = enter(c); if (rc) return rc;
     if ((rc = drain_frames(c))) return rc;  // frames in flight may sample this image
     PTR_HIP_CHECK(c, hipMemcpyAsync(im->ptr, texels, (size_t)im->w * im->h * texel_size(im->format), hipMemcpyHostToDevice, c->stream));
     if (im->tiled) PTR_HIP_CHECK(c, ptr::launch_tile_rgba8(c->stream, im->ptr, im->tiled, im->w, im->h));
@@ -991,7 +1085,7 @@ int ptr_image_read(ptr_ctx* c, ptr_handle h, void* texels) {
     ImageRec* im = find_image(c, h);
     if (!im) return fail(c, PTR_E_INVALID, "ptr_image_read: unknown image %u", h);
     if (!texels) return fail(c, PTR_E_INVALID, "ptr_image_read: null texels");
-    int rc = bind_device(c); if (rc) return rc;
+    int rc = enter(c); if (rc) return rc;
     PTR_HIP_CHECK(c, hipMemcpyAsync(texels, im->ptr, (size_t)im->w * im->h * texel_size(im->format), hipMemcpyDeviceToHost, c->stream));
     PTR_HIP_CHECK(c, hipStreamSynchronize(c->stream));
     return take_fault(c);
@@ -1008,7 +1102,7 @@ int ptr_device_function(ptr_ctx* c, const char* name, const uint32_t* in, uint32
         return fail(c, PTR_E_INVALID, "ptr_device_function: '%s' takes %u words and returns %u, got %u and %u", name, want_in, want_out, in_words, out_words);
     if (count == 0) return PTR_OK;
     if (count > (1u << 24)) return fail(c, PTR_E_RANGE, "ptr_device_function: at most %u records per call", 1u << 24);
-    int rc = bind_device(c); if (rc) return rc;
+    int rc = enter(c); if (rc) return rc;
     uint32_t *d_in = nullptr, *d_out = nullptr;
     const size_t in_bytes = (size_t)count * in_words * 4, out_bytes = (size_t)count * out_words * 4;
     PTR_HIP_CHECK(c, hipMalloc((void**)&d_in, in_bytes));
@@ -1055,7 +1149,7 @@ int ptr_bvh_bind_flat(ptr_ctx* c, ptr_handle threaded_nodes, ptr_handle flat) {
         if (!f) return fail(c, PTR_E_INVALID, "ptr_bvh_bind_flat: unknown flat buffer %u", flat);
         if (f->size < 64) return fail(c, PTR_E_INVALID, "ptr_bvh_bind_flat: flat buffer shorter than the 64-byte header");
     }
-    int rc = bind_device(c); if (rc) return rc;
+    int rc = enter(c); if (rc) return rc;
     if ((rc = drain_frames(c))) return rc;
     b->flat = flat;
     return PTR_OK;
@@ -1071,7 +1165,7 @@ int ptr_bvh_bind_instances(ptr_ctx* c, ptr_handle flat, ptr_handle instances) {
         if (t->size < 64) return fail(c, PTR_E_INVALID, "ptr_bvh_bind_instances: instance buffer shorter than the 64-byte header");
         if (instances == flat) return fail(c, PTR_E_INVALID, "ptr_bvh_bind_instances: the instance buffer cannot be the flat buffer itself");
     }
-    int rc = bind_device(c); if (rc) return rc;
+    int rc = enter(c); if (rc) return rc;
     if ((rc = drain_frames(c))) return rc;
     f->instances = instances;
     return PTR_OK;
@@ -1089,7 +1183,7 @@ int ptr_bvh_build_flat(ptr_ctx* c, ptr_handle indices, ptr_handle positions, uin
     if (ib->size < index_bytes) return fail(c, PTR_E_RANGE, "ptr_bvh_build_flat: the index buffer holds fewer than %u triangles of %d words", triangle_count, c->opt_index_words);
     const uint64_t vertices = pb->size / 12u;
     if (vertices == 0) return fail(c, PTR_E_RANGE, "ptr_bvh_build_flat: the position buffer holds no vertex");
-    int rc = bind_device(c); if (rc) return rc;
+    int rc = enter(c); if (rc) return rc;
     ptr::SceneView sv{};
     sv.indices = (const uint32_t*)ib->ptr;
     sv.positions = (const float*)pb->ptr;
@@ -1121,7 +1215,7 @@ int ptr_bvh_flat_set_reference_ranks(ptr_ctx* c, ptr_handle flat, ptr_handle thr
     BufferRec* t = find_buffer(c, threaded_nodes);
     if (!f || !t) return fail(c, PTR_E_INVALID, "ptr_bvh_flat_set_reference_ranks: unknown flat or node buffer");
     if (triangle_count == 0) return fail(c, PTR_E_INVALID, "ptr_bvh_flat_set_reference_ranks: no triangles");
-    int rc = bind_device(c); if (rc) return rc;
+    int rc = enter(c); if (rc) return rc;
     if ((rc = drain_frames(c))) return rc;
     struct Header { uint32_t magic, version, node_count, triangle_count; uint64_t nodes_offset, triangles_offset; int32_t root; uint32_t max_depth; float bounds[6]; } hd;
     if (f->size < sizeof hd) return fail(c, PTR_E_STATE, "ptr_bvh_flat_set_reference_ranks: blob shorter than its header");
@@ -1145,9 +1239,10 @@ int ptr_dispatch(ptr_ctx* c, const char* kernel, const uint8_t constants[64], ui
     if (gx == 0 || gy == 0 || gz == 0) return PTR_OK;
     if ((uint64_t)gx * gy > 0x7fffffffull) return fail(c, PTR_E_RANGE, "ptr_dispatch: too many workgroups");
     // the shaders only read gl_GlobalInvocationID.xy: z slices would repeat the same work, one slice is run
-    if (!strcmp(kernel, "compute")) return dispatch_compute(c, constants, gx, gy, 0);
-    if (!strcmp(kernel, "compute.megakernel")) return dispatch_compute(c, constants, gx, gy, 1);
-    if (!strcmp(kernel, "compute.wavefront")) return dispatch_compute(c, constants, gx, gy, 2);
+    if (!strcmp(kernel, "compute")) return dispatch_or_hold(c, constants, gx, gy, 0);
+    if (!strcmp(kernel, "compute.megakernel")) return dispatch_or_hold(c, constants, gx, gy, 1);
+    if (!strcmp(kernel, "compute.wavefront")) return dispatch_or_hold(c, constants, gx, gy, 2);
+    if ((rc = flush_pending(c))) return rc;
     if (!strcmp(kernel, "tonemapping")) {
         const ParsedConstants k = parse_constants(constants);
         if (!buffer_at(c, k.addr[0], sizeof(ptr::SceneMeta))) return fail(c, PTR_E_STATE, "constant block: scene metadata address is not inside a registered buffer");
@@ -1175,7 +1270,7 @@ int ptr_dispatch(ptr_ctx* c, const char* kernel, const uint8_t constants[64], ui
 int ptr_dispatch_static(ptr_ctx* c, const char* kernel, const uint8_t constants[64], uint32_t gx, uint32_t gy, uint32_t gz) {
     if (!c) return PTR_E_INVALID;
     if (!kernel || !constants) return fail(c, PTR_E_INVALID, "ptr_dispatch_static: null kernel name or constants");
-    int rc = bind_device(c); if (rc) return rc;
+    int rc = enter(c); if (rc) return rc;
     if (gx == 0 || gy == 0 || gz == 0) return PTR_OK;
     if ((uint64_t)gx * gy > 0x7fffffffull) return fail(c, PTR_E_RANGE, "ptr_dispatch_static: too many workgroups");
     if (!strcmp(kernel, "compute")) return dispatch_compute(c, constants, gx, gy, 0, true);
@@ -1188,6 +1283,7 @@ int ptr_set_partition(ptr_ctx* c, uint32_t rank, uint32_t world, uint32_t stripe
     if (!c) return PTR_E_INVALID;
     if (world == 0 || rank >= world) return fail(c, PTR_E_INVALID, "ptr_set_partition: rank %u / world %u", rank, world);
     if (stripe_rows == 0 || (stripe_rows & 7u) || stripe_rows > 65536u) return fail(c, PTR_E_INVALID, "ptr_set_partition: stripe_rows must be a positive multiple of 8, 65536 at most");
+    int rc = enter(c); if (rc) return rc;
     c->part_rank = rank; c->part_world = world; c->part_stripe = stripe_rows;
     return PTR_OK;
 }
@@ -1203,7 +1299,7 @@ static int stripes_copy(ptr_ctx* c, const char* who, ptr_handle image, uint32_t 
     const uint64_t chunk_bytes = ((stripes + world - 1u) / world) * stripe_rows * im->w * 16u;
     if (chunk_bytes * ranks > b->size) return fail(c, PTR_E_RANGE, "%s: the buffer holds %zu bytes, %llu needed", who, b->size, (unsigned long long)(chunk_bytes * ranks));
     if (chunk_bytes * ranks / 16u > 0xffffffffull * 256ull) return fail(c, PTR_E_RANGE, "%s: frame too large", who);
-    int rc = bind_device(c); if (rc) return rc;
+    int rc = enter(c); if (rc) return rc;
     PTR_HIP_CHECK(c, ptr::launch_stripes_copy(c->stream, (float4*)im->ptr, im->w, im->h, stripe_rows, world, rank, ranks, (float4*)b->ptr, unpack));
     if (!unpack) b->generation = ++c->write_epoch;
     return PTR_OK;
@@ -1220,12 +1316,15 @@ int ptr_image_unpack_stripes(ptr_ctx* c, ptr_handle image, uint32_t world, uint3
 int ptr_set_sample_partition(ptr_ctx* c, uint32_t rank, uint32_t world) {
     if (!c) return PTR_E_INVALID;
     if (world == 0 || rank >= world) return fail(c, PTR_E_INVALID, "ptr_set_sample_partition: rank %u / world %u", rank, world);
+    int rc = enter(c); if (rc) return rc;
     c->sample_rank = rank; c->sample_world = world;
     return PTR_OK;
 }
 
 int ptr_set_option(ptr_ctx* c, const char* key, int value) {
     if (!c || !key) return PTR_E_INVALID;
+    // (a frame loop sets "dispatch.samples" before every dispatch: the same value again changes nothing)
+    if (!(!strcmp(key, "dispatch.samples") && value == c->opt_dispatch_samples)) { int rc = enter(c); if (rc) return rc; }
     if (!strcmp(key, "extend.refill")) {
         if (value != 8 && value != 16 && value != 32 && value != 64) return fail(c, PTR_E_INVALID, "extend.refill: 8, 16, 32 or 64 idle lanes");
         c->opt_extend_refill = value;
@@ -1263,7 +1362,7 @@ int ptr_set_option(ptr_ctx* c, const char* key, int value) {
     }
     if (!strcmp(key, "frames.in_flight")) {
         if (value < 1 || value > ptr_ctx::kMaxFrameSlots) return fail(c, PTR_E_INVALID, "frames.in_flight: 1..%d", ptr_ctx::kMaxFrameSlots);
-        int rc = bind_device(c); if (rc) return rc;
+        int rc = enter(c); if (rc) return rc;
         if ((rc = drain_frames(c))) return rc;
         c->opt_frames_in_flight = value;
         return PTR_OK;
@@ -1276,6 +1375,11 @@ int ptr_set_option(ptr_ctx* c, const char* key, int value) {
     if (!strcmp(key, "scene.validate")) {
         if (value != 0 && value != 1) return fail(c, PTR_E_INVALID, "scene.validate: 0 or 1");
         c->opt_validate = value;
+        return PTR_OK;
+    }
+    if (!strcmp(key, "dispatch.coalesce")) {
+        if (value < 1 || value > 64) return fail(c, PTR_E_INVALID, "dispatch.coalesce: 1..64");
+        c->opt_coalesce = value;
         return PTR_OK;
     }
     if (!strcmp(key, "dispatch.samples")) {
@@ -1299,19 +1403,21 @@ int ptr_set_option(ptr_ctx* c, const char* key, int value) {
 int ptr_set_capture(ptr_ctx* c, ptr_handle buffer) {
     if (!c) return PTR_E_INVALID;
     if (buffer != 0 && !find_buffer(c, buffer)) return fail(c, PTR_E_INVALID, "ptr_set_capture: unknown buffer %u", buffer);
+    int rc = enter(c); if (rc) return rc;
     c->capture = buffer;
     return PTR_OK;
 }
 
 int ptr_stats_enable(ptr_ctx* c, int on) {
     if (!c) return PTR_E_INVALID;
+    int rc = enter(c); if (rc) return rc;
     c->stats_on = on != 0;
     return PTR_OK;
 }
 
 int ptr_stats_read(ptr_ctx* c, uint64_t out[8], int reset) {
     if (!c || !out) return PTR_E_INVALID;
-    int rc = bind_device(c); if (rc) return rc;
+    int rc = enter(c); if (rc) return rc;
     unsigned long long host[8];
     PTR_HIP_CHECK(c, hipMemcpyAsync(host, c->d_stats, sizeof host, hipMemcpyDeviceToHost, c->stream));
     PTR_HIP_CHECK(c, hipStreamSynchronize(c->stream));
@@ -1326,13 +1432,14 @@ int ptr_stats_read(ptr_ctx* c, uint64_t out[8], int reset) {
 
 int ptr_profile_enable(ptr_ctx* c, int on) {
     if (!c) return PTR_E_INVALID;
+    int rc = enter(c); if (rc) return rc;
     c->profile_on = on != 0;
     return PTR_OK;
 }
 
 int ptr_profile_read(ptr_ctx* c, const char* name, uint64_t* launches, double* total_ms, int reset) {
     if (!c || !name) return PTR_E_INVALID;
-    int rc = bind_device(c); if (rc) return rc;
+    int rc = enter(c); if (rc) return rc;
     drain_profile(c);
     auto it = c->profile.find(name);
     if (launches) *launches = it == c->profile.end() ? 0 : it->second.launches;

@@ -64,6 +64,7 @@ struct SceneView {
     uint32_t index_words;      // 3: the reference's packed index words; 4: v0, v1, v2, material as plain words
     const float4* shade_records;  // optional: kShadeRecordVec4 float4 per triangle, see ShadeInputs / gather_shade_inputs
     uint32_t shade_record_count;
+    uint32_t prev_image_plus_one;  // several samples per dispatch: image index + 1 that receives the result of the last sample but one (0: none)
     const float4* instance_records;  // optional (two-level scenes): 4 float4 per instance, rows of world-to-object first
     uint32_t instance_count;
     uint32_t object_triangles;       // two-level scenes: captured primitive ids read instance * object_triangles + primitive
@@ -439,21 +440,28 @@ PTR_DEV void image_store(const ImageDesc& im, int32_t x, int32_t y, f3 c) {
 // dispatches with the host's image swap in between (src/main.cpp:416) leave in the image written last.  Each frame decodes
 // what the frame before stored -- the encode / decode round trip is not the identity in fp32, so it is done, not skipped --
 // and a pixel outside the images reads 0 every time, as image_load gives it.  Both images must have the same extent.
-PTR_DEV void accumulate_pixel_chain(const ImageDesc& acc, const ImageDesc& out, int32_t cx, int32_t cy, int32_t downscale,
+// `before_last` (optional) receives what the frame before the last one stored -- the image the last frame read -- so that BOTH
+// images end up as `count` single dispatches leave them (coalesced dispatches, "dispatch.coalesce").
+PTR_DEV void accumulate_pixel_chain(const ImageDesc& acc, const ImageDesc& out, const ImageDesc* before_last, int32_t cx, int32_t cy, int32_t downscale,
                                     uint32_t first_sample_index, uint32_t count, const float4* samples, size_t stride) {
     const f4 a = image_load(acc, cx, cy);
     f3 stored = mk3(a.x, a.y, a.z);
     const bool inside = out.data != nullptr && cx >= 0 && cy >= 0 && (uint32_t)cx < out.width && (uint32_t)cy < out.height;
-    f3 o = stored;
+    f3 o = stored, previous = stored;
     for (uint32_t k = 0; k < count; k++) {
         const float4 s4 = samples[(size_t)k * stride];
         const float spp_scale = 1.0f / (float)(first_sample_index + k);
         const f3 prev = srgb_to_linear(stored);
+        previous = o;
         o = linear_to_srgb(mk3(mixf(prev.x, s4.x, spp_scale), mixf(prev.y, s4.y, spp_scale), mixf(prev.z, s4.z, spp_scale)));
         stored = inside ? o : mk3(0.0f, 0.0f, 0.0f);
     }
     for (int32_t i = 0; i < downscale; i++)
-        for (int32_t j = 0; j < downscale; j++) image_store(out, cx + i, cy + j, o);
+        for (int32_t j = 0; j < downscale; j++) {
+            // `before_last` may be the image `acc` was read from: this thread read its texel above and is the only one to write it
+            if (before_last != nullptr && count >= 2u) image_store(*before_last, cx + i, cy + j, previous);
+            image_store(out, cx + i, cy + j, o);
+        }
 }
 
 PTR_DEV void accumulate_pixel(const ImageDesc& acc, const ImageDesc& out, int32_t cx, int32_t cy, int32_t downscale,

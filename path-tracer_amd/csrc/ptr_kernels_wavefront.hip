@@ -659,7 +659,8 @@ __global__ __launch_bounds__(256) void ptr_wf_accumulate(SceneView sv, Wavefront
     const uint32_t gy = (wave / tiles_x) * 8u + (lane >> 3);
     if (gx >= domain_w || gy >= domain_h || !owns_row(sv, gy)) return;
     if (sv.batch_samples > 1u) {
-        accumulate_pixel_chain(sv.images[sv.accumulation_index], sv.images[sv.output_index], (int32_t)gx * m.downscale_factor,
+        accumulate_pixel_chain(sv.images[sv.accumulation_index], sv.images[sv.output_index],
+                               sv.prev_image_plus_one ? &sv.images[sv.prev_image_plus_one - 1u] : nullptr, (int32_t)gx * m.downscale_factor,
                                (int32_t)gy * m.downscale_factor, m.downscale_factor, m.sample_index, sv.batch_samples,
                                w.samples + (gy * m.width + gx), (size_t)m.width * m.height);
         return;

@@ -115,6 +115,7 @@ const char kUsage[] =
     "            --copies NX NZ (the scene placed on a grid through a top-level tree)   --gpu-bvh (tree built on the GPU)\n"
     "  frame     --width W --height H --spp N --max-bounce N --min-bounce N --downscale N --dof 0|1 --debug-bvh 0|1\n"
     "            --samples-per-dispatch N (1..64 samples per dispatch; same image)   --pipeline compute|compute.megakernel|compute.wavefront\n"
+    "            --coalesce N (one dispatch per sample as the reference issues them, rendered N at a time by the library; same image)\n"
     "  camera    --pos X Y Z --target X Y Z --fov DEGREES --aperture A --focus DISTANCE\n"
     "  output    --out file.ppm | file.png (8 bits per channel, 256 * clamp(c, 0, 0.999)) | any other name (\"PTRF w h\\n\" + the float RGBA image)\n"
     "  GPUs      --gpus N (one process per GPU is started)   --partition tiles|samples   --stripe-rows N (a multiple of 8)\n"
@@ -124,7 +125,7 @@ int main(int argc, char** argv) {
     std::string scene_path, out_path, pipeline = "compute";
     bool apply_transforms = false, gpu_bvh = false, instanced = false;
     uint32_t copies_x = 1, copies_z = 1;
-    uint32_t gpus = 1, stripe_rows = 8, samples_per_dispatch = 1;
+    uint32_t gpus = 1, stripe_rows = 8, samples_per_dispatch = 1, coalesce = 1;
     int rank = -1, device = -1;
     bool transport_given = false;   // with --gpus 1: run the exchange anyway, alone (rehearses the RCCL calls on a one-GPU box)
     std::string partition = "tiles", transport = "rccl", rendezvous;
@@ -147,6 +148,7 @@ int main(int argc, char** argv) {
         else if (is("--rendezvous")) rendezvous = next();
         else if (is("--stripe-rows")) stripe_rows = (uint32_t)std::atoi(next());
         else if (is("--samples-per-dispatch")) samples_per_dispatch = (uint32_t)std::atoi(next());
+        else if (is("--coalesce")) coalesce = (uint32_t)std::atoi(next());
         else if (is("--out")) out_path = next();
         else if (is("--pipeline")) pipeline = next();
         else if (is("--width")) width = (uint32_t)std::atoi(next());
@@ -209,6 +211,10 @@ int main(int argc, char** argv) {
 
         const auto t0 = std::chrono::steady_clock::now();
         if (samples_per_dispatch == 0 || samples_per_dispatch > 64) throw std::runtime_error("--samples-per-dispatch: 1..64");
+        if (coalesce == 0 || coalesce > 64) throw std::runtime_error("--coalesce: 1..64");
+        // the loop below stays the reference's (one dispatch and one image swap per sample); the library holds the
+        // dispatches back and renders `coalesce` of them at a time
+        hiprenderer::check(ptr_set_option(hiprenderer::api, "dispatch.coalesce", (int)coalesce), "ptr_set_option");
         for (uint32_t frame = 0; frame < frames;) {
             // one dispatch = the next `batch` samples, accumulated in order; the images swap once per dispatch
             const uint32_t batch = std::min(samples_per_dispatch, frames - frame);
@@ -224,6 +230,7 @@ int main(int argc, char** argv) {
             renderer.finish_frame();
         }
         hiprenderer::check(ptr_set_option(hiprenderer::api, "dispatch.samples", 1), "ptr_set_option");
+        hiprenderer::check(ptr_set_option(hiprenderer::api, "dispatch.coalesce", 1), "ptr_set_option");   // runs what is still held back
         if (exchange && tiles) {
             // one all-gather of the owned stripes; after the swap the last written image is `accumulation_texture`
             const size_t chunk_bytes = stripe_chunk_texels(width, height, stripe_rows, gpus) * 16;

@@ -44,6 +44,7 @@ def lib():
         "ptr_ctx_destroy": [vp],
         "ptr_ctx_set_stream": [vp, vp],
         "ptr_sync": [vp],
+        "ptr_flush": [vp],
         "ptr_buffer_create": [vp, sz, P(u32)],
         "ptr_buffer_destroy": [vp, u32],
         "ptr_buffer_write": [vp, u32, vp, sz, sz],
@@ -87,7 +88,7 @@ def lib():
     return L
 
 
-ABI_SYMBOLS = ["ptr_ctx_create", "ptr_ctx_destroy", "ptr_ctx_set_stream", "ptr_last_error", "ptr_sync", "ptr_buffer_create",
+ABI_SYMBOLS = ["ptr_ctx_create", "ptr_ctx_destroy", "ptr_ctx_set_stream", "ptr_last_error", "ptr_sync", "ptr_flush", "ptr_buffer_create",
                "ptr_buffer_destroy", "ptr_buffer_write", "ptr_buffer_read", "ptr_buffer_address", "ptr_sampler_create",
                "ptr_image_create", "ptr_image_wrap", "ptr_image_destroy", "ptr_image_upload", "ptr_image_read",
                "ptr_image_index", "ptr_sampler_index", "ptr_image_address", "ptr_bvh_bind_flat", "ptr_bvh_bind_instances", "ptr_dispatch", "ptr_dispatch_static",
@@ -127,6 +128,10 @@ class Context:
 
     def sync(self):
         self._check(self._L.ptr_sync(self.handle))
+
+    def flush(self):
+        """Enqueues the dispatches held back under "dispatch.coalesce" without waiting for them."""
+        self._check(self._L.ptr_flush(self.handle))
 
     # ---- factories named after the reference's vkrenderer statics ----
     def create_buffer(self, size):

@@ -148,6 +148,21 @@ def test_headless_several_samples_per_dispatch(tmp_path):
     assert np.array_equal(read_ptrf(out_file), ref)
 
 
+@pytest.mark.parametrize("extra", [("--coalesce", "3"), ("--coalesce", "4", "--gpus", "2", "--transport", "file", "--partition", "tiles")])
+def test_headless_reference_loop_with_held_back_dispatches(tmp_path, extra):
+    """--coalesce N: the driver's loop stays the reference's (write sample_index, dispatch, swap, once per sample); the library
+    renders N dispatches at a time.  --spp 7: the image of seven single-sample frames, also with the tile partition on top."""
+    W, H, SPP = 72, 40, 7
+    b = make_bundle("atrium", 3000, W, H, max_bounce=4)
+    scene_file = str(tmp_path / "scene.ptrscene")
+    out_file = str(tmp_path / "out.pfm")
+    scenes.save_ptrscene(b, scene_file)
+    r = subprocess.run(headless_cmd(b, scene_file, out_file, W, H, SPP, *extra), capture_output=True, text=True, timeout=180)
+    assert r.returncode == 0, r.stderr
+    ref, _, _ = oracle_frames(b, SPP, use_flat=True)
+    assert np.array_equal(read_ptrf(out_file), ref)
+
+
 @pytest.mark.parametrize("ranks,transport", [(2, "file"), (3, "file"), (1, "rccl")])
 def test_headless_tile_partition_over_processes(tmp_path, ranks, transport):
     """--gpus N --partition tiles: N processes (here all on the one GPU, exchanging through the file transport -- RCCL refuses

@@ -768,3 +768,111 @@ def test_stripe_pack_and_unpack_kernels(ctx, width, height, world, stripe):
         t.destroy()
     for b in (packed, gathered):
         b.destroy()
+
+
+# ---- "dispatch.coalesce": the reference's frame loop as it is, rendered as batched dispatches ----
+def _both_images(loop):
+    return loop.latest().read(), loop.output.read()
+
+
+@pytest.mark.parametrize("frames,hold", [(1, 8), (2, 8), (3, 8), (8, 8), (11, 8), (7, 2), (20, 64)])
+def test_coalesced_dispatches_leave_both_images_as_single_dispatches_do(ctx, frames, hold):
+    """K single-sample dispatches with the image swap after each, once as they are and once held back and rendered as dispatches
+    of up to `hold` samples: the image written last AND the one written before it are equal bit for bit."""
+    from path_tracer_amd import hip
+    b = make_bundle("atrium", 30_000, 96, 72, max_bounce=3)
+    gs = hip.GpuScene(ctx, b, b["nodes"], b["flat"], b["meta"])
+    plain = hip.FrameLoop(ctx, gs, 96, 72, "compute")
+    for _ in range(frames):
+        plain.frame()
+    want_last, want_other = _both_images(plain)
+    held = hip.FrameLoop(ctx, gs, 96, 72, "compute")
+    ctx.set_option("dispatch.coalesce", hold)
+    ctx.profile_read(reset=True)
+    ctx.profile_enable(True)
+    try:
+        for _ in range(frames):
+            held.frame()
+        got_last, got_other = _both_images(held)      # the read runs what is still held back
+    finally:
+        ctx.set_option("dispatch.coalesce", 1)
+        ctx.profile_enable(False)
+    # the frames really were rendered as ceil(frames / hold) dispatches
+    assert ctx.profile_read(reset=True)["wavefront.generate"]["launches"] == -(-frames // hold)
+    assert np.array_equal(got_last, want_last)
+    assert np.array_equal(got_other, want_other)
+    img, _, _ = oracle_frames(b, frames, use_flat=True, materials=gs.materials_host, textures=gs.texture_table)
+    assert np.array_equal(got_last, img)
+
+
+def test_coalescing_stops_where_the_chain_breaks(ctx):
+    """A camera move, a read of the image in between, a write to a buffer the frames read, a restart of the accumulation, a
+    downscaled frame: each ends the batch being held back, and the images are those of the plain loop."""
+    from path_tracer_amd import hip
+    b = make_bundle("street_interior", 30_000, 80, 64, max_bounce=3)
+    gs = hip.GpuScene(ctx, b, b["nodes"], b["flat"], b["meta"])
+
+    def run(hold):
+        loop = hip.FrameLoop(ctx, gs, 80, 64, "compute")
+        gs.set_meta(b["meta"])
+        ctx.set_option("dispatch.coalesce", hold)
+        seen = []
+        try:
+            for _ in range(3):
+                loop.frame()
+            gs.update_meta(max_bounce=2)                       # another scene state: not the same chain any more
+            for _ in range(3):
+                loop.frame()
+            seen.append(loop.latest().read())                  # a read in the middle of a batch
+            for _ in range(2):
+                loop.frame()
+            mats = gs.materials_buffer.read(np.uint8)
+            gs.materials_buffer.write(mats)                    # a write to a buffer the held-back frames read
+            for _ in range(2):
+                loop.frame()
+            loop.reset()                                       # sample_index back to 1: a new chain on the old images
+            for _ in range(4):
+                loop.frame()
+            gs.update_meta(downscale_factor=2)
+            for _ in range(3):
+                loop.frame()
+            seen.extend(_both_images(loop))
+        finally:
+            ctx.set_option("dispatch.coalesce", 1)
+            gs.set_meta(b["meta"])
+        return seen
+
+    for want, got in zip(run(1), run(6)):
+        assert np.array_equal(want, got)
+
+
+def test_a_held_back_dispatch_runs_before_anything_else_sees_its_images(ctx):
+    from path_tracer_amd import hip
+    b = make_bundle("atrium", 20_000, 64, 48, max_bounce=2)
+    gs = hip.GpuScene(ctx, b, b["nodes"], b["flat"], b["meta"])
+    loop = hip.FrameLoop(ctx, gs, 64, 48, "compute")
+    tone = ctx.create_2d_texture(64, 48, hip.FORMAT_RGBA32_SFLOAT)
+    rp = ctx.create_compute_renderpass()
+    rp.set_pipeline("tonemapping")
+    rp.set_constant(0, gs.scene_buffer)
+    rp.set_ouput_texture(tone)
+    rp.set_dispatch_size((64 + 7) // 8, (48 + 7) // 8, 1)
+    ctx.set_option("dispatch.coalesce", 16)
+    try:
+        for _ in range(5):
+            loop.frame()
+        rp.set_constant(60, loop.latest())
+        rp.execute()                                           # another kernel: the five frames it reads run first
+        got5 = tone.read()
+        for _ in range(3):
+            loop.frame()
+        ctx.flush()                                            # enqueued now, not waited for
+        rp.set_constant(60, loop.latest())
+        rp.execute()
+        got8 = tone.read()
+    finally:
+        ctx.set_option("dispatch.coalesce", 1)
+    for frames, got in ((5, got5), (8, got8)):
+        want, _, _ = oracle_frames(b, frames, use_flat=True, materials=gs.materials_host, textures=gs.texture_table)
+        assert np.array_equal(got[..., :3], np.sqrt(want[..., :3])), frames
+    tone.destroy()
