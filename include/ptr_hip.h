@@ -129,7 +129,8 @@ int ptr_dispatch(ptr_ctx* ctx, const char* kernel, const uint8_t constants[64], 
  * step gathers per hit, same results).  The frame runs start to end on the context's stream ("frames.in_flight" does not
  * apply; no per-kernel profile events), on a smaller persistent traversal grid than ptr_dispatch uses.  Every call on a GPU
  * shares that GPU's array: calls that can overlap on one GPU (two contexts, or one context moved between streams without
- * a ptr_sync) race.  kernel: "compute", "compute.megakernel" (uses no scratch at all) or "compute.wavefront". */
+ * a ptr_sync) race.  kernel: "compute", "compute.megakernel" (uses no scratch at all) or "compute.wavefront".  While dispatches
+ * are held back under "dispatch.coalesce" the call fails with PTR_E_STATE (running them would allocate): ptr_flush first. */
 int ptr_dispatch_static(ptr_ctx* ctx, const char* kernel, const uint8_t constants[64], uint32_t groups_x, uint32_t groups_y,
                         uint32_t groups_z);
 

@@ -1270,7 +1270,9 @@ int ptr_dispatch(ptr_ctx* c, const char* kernel, const uint8_t constants[64], ui
 int ptr_dispatch_static(ptr_ctx* c, const char* kernel, const uint8_t constants[64], uint32_t gx, uint32_t gy, uint32_t gz) {
     if (!c) return PTR_E_INVALID;
     if (!kernel || !constants) return fail(c, PTR_E_INVALID, "ptr_dispatch_static: null kernel name or constants");
-    int rc = enter(c); if (rc) return rc;
+    int rc = bind_device(c); if (rc) return rc;
+    // running held-back dispatches here would allocate their scratch: the caller runs them first, where it may
+    if (c->pending.active) return fail(c, PTR_E_STATE, "ptr_dispatch_static: dispatches are being held back (\"dispatch.coalesce\"); call ptr_flush or ptr_sync first");
     if (gx == 0 || gy == 0 || gz == 0) return PTR_OK;
     if ((uint64_t)gx * gy > 0x7fffffffull) return fail(c, PTR_E_RANGE, "ptr_dispatch_static: too many workgroups");
     if (!strcmp(kernel, "compute")) return dispatch_compute(c, constants, gx, gy, 0, true);

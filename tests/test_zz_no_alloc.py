@@ -55,6 +55,17 @@ def test_static_dispatch_equals_the_allocating_dispatch_twice_in_a_row_the_secon
 
         # back and forth between the two entry points on one context: neither disturbs the other
         assert np.array_equal(render(ctx, gs_big, 200, 120, 2, static=False), render(ctx, gs_big, 200, 120, 2, static=True))
+
+        # dispatches held back under "dispatch.coalesce" would have to allocate when they run: the static entry point does not
+        # run them on the quiet, it says what to call first
+        ctx.set_option("dispatch.coalesce", 8)
+        held = hip.FrameLoop(ctx, gs_small, 56, 40, "compute")
+        held.frame()
+        with pytest.raises(hip.HipError, match="held back"):
+            ctx.dispatch_static("compute", held.renderpass.constants, *held.renderpass.group_count)
+        ctx.flush()
+        ctx.dispatch_static("compute", held.renderpass.constants, *held.renderpass.group_count)
+        ctx.set_option("dispatch.coalesce", 1)
     finally:
         ctx.close()
 
