@@ -85,6 +85,7 @@ struct ptr_ctx {
         hipEvent_t consumed = nullptr;   // recorded on the slot's stream after the frame's accumulate step
         bool in_flight = false;          // `consumed` has been recorded for a frame of this slot
         uint64_t synced_epoch = 0;       // value of write_epoch when this slot's stream last waited for the context's stream
+        uint64_t ready_epoch = 0;        // value of write_epoch when `ready` was last recorded
         ptr::WavefrontScratch scratch{};
         void* scratch_block = nullptr;
         ptr_handle reads[9] = {};        // buffers the slot's last frame reads (hazard check of later writes)
@@ -714,9 +715,22 @@ int dispatch_compute(ptr_ctx* c, const uint8_t constants[64], uint32_t gx, uint3
         if (flat_buf->generation > newest) newest = flat_buf->generation;
         if (top_buf && top_buf->generation > newest) newest = top_buf->generation;
         if (newest > slot.synced_epoch) {
-            PTR_HIP_CHECK(c, hipEventRecord(slot.ready, c->stream));
+            if (slot.ready_epoch < newest) {
+                // This point of the context's stream is marked for EVERY slot that is behind, not only this one: once this
+                // frame's accumulate step is on that stream, a mark made later would also stand behind it, and the next
+                // frame -- on the other slot, and just as much behind after a ptr_sync or an upload -- would wait for this
+                // whole frame instead of for the inputs.
+                for (int i = 0; i < c->opt_frames_in_flight; i++) {
+                    ptr_ctx::FrameSlot& o = c->slots[i];
+                    if ((rc = ensure_slot(c, o))) return rc;
+                    if (o.synced_epoch < c->write_epoch) {
+                        PTR_HIP_CHECK(c, hipEventRecord(o.ready, c->stream));
+                        o.ready_epoch = c->write_epoch;
+                    }
+                }
+            }
             PTR_HIP_CHECK(c, hipStreamWaitEvent(ts, slot.ready, 0));
-            slot.synced_epoch = c->write_epoch;
+            slot.synced_epoch = slot.ready_epoch;
         }
     }
     PTR_HIP_CHECK(c, hipMemsetAsync(w.counters, 0, 64 * sizeof(uint32_t), ts));

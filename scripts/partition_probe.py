@@ -24,23 +24,29 @@ def main():
     sc, nodes, flat, meta, _ = bench.build_scene(args, 0)
     ctx = hip.Context(0)
     gpu = hip.GpuScene(ctx, sc, nodes, flat, meta)
-    base = {}
-    for per in args.per_dispatch:
-        for world in args.worlds:
-            ctx.set_partition(0, world, args.stripe_rows)
-            loop = hip.FrameLoop(ctx, gpu, args.width, args.height, args.pipeline, samples_per_dispatch=min(64, per))
-            loop.frames(2 * min(64, per)); ctx.sync()
-            best = 1e9
-            for _ in range(args.rounds):
-                loop.reset()
-                t0 = time.perf_counter()
-                loop.frames(args.steps)
-                ctx.sync()
-                best = min(best, time.perf_counter() - t0)
-            base.setdefault(per, best if world == 1 else None)
-            t1 = base[per] or best
-            print(f"samples per dispatch {min(64, per):2d}  world {world}: {best * 1e3:7.3f} ms for {args.steps} steps"
-                  f"   render-only efficiency {t1 / (world * best):.3f}", flush=True)
+    def measure(world, per):
+        ctx.set_partition(0, world, args.stripe_rows)
+        loop = hip.FrameLoop(ctx, gpu, args.width, args.height, args.pipeline, samples_per_dispatch=min(64, per))
+        loop.frames(2 * min(64, per)); ctx.sync()
+        best = 1e9
+        for _ in range(args.rounds):
+            loop.reset()
+            t0 = time.perf_counter()
+            loop.frames(args.steps)
+            ctx.sync()
+            best = min(best, time.perf_counter() - t0)
+        return best
+
+    # T_1: the whole frames on one GPU, with the dispatch size that suits ONE GPU best (not the one the partition is tried with)
+    t1 = {per: measure(1, per) for per in args.per_dispatch}
+    for per, t in t1.items():
+        print(f"world 1  samples per dispatch {min(64, per):2d}: {t * 1e3:7.3f} ms for {args.steps} steps", flush=True)
+    t1_best = min(t1.values())
+    for world in [w for w in args.worlds if w > 1]:
+        for per in args.per_dispatch:
+            t = measure(world, per)
+            print(f"world {world}  samples per dispatch {min(64, per):2d}: {t * 1e3:7.3f} ms for {args.steps} steps"
+                  f"   render-only efficiency {t1_best / (world * t):.3f} (against the best one-GPU time, {t1_best * 1e3:.3f} ms)", flush=True)
     ctx.set_partition(0, 1, 8)
     ctx.close()
 
