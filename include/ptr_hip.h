@@ -194,6 +194,16 @@ int ptr_set_sample_partition(ptr_ctx* ctx, uint32_t rank, uint32_t world);
  *                              tile partition still has a full GPU's worth of rays.  Needs output and accumulation images of
  *                              the same extent; not available with ptr_set_capture, the megakernel or debug_bvh
  *                              (PTR_E_UNSUPPORTED / PTR_E_STATE).
+ *      "bvh.auto_flatten"      0 (default) | 1: a "compute" dispatch whose bvh buffer has no flattened layout bound -- the caller
+ *                              uploaded the reference's seven buffers and nothing else -- builds one on the GPU from the
+ *                              dispatch's index and position buffers (as ptr_bvh_build_flat does), takes the tie-break ranks
+ *                              from the threaded tree (ptr_bvh_flat_set_reference_ranks), binds it and runs the wavefront
+ *                              pipeline instead of the megakernel: same image, about 50 times the speed on the benchmark scene,
+ *                              128 + 80 bytes of device memory per triangle, tens of milliseconds once.  The layout is rebuilt
+ *                              when the node, index or position buffer is written again, and replaced by a layout the caller
+ *                              binds.  Needs the three buffers addressed from their start and the full 2N-1-node tree; a
+ *                              dispatch that does not qualify, or whose tree the builder cannot handle, runs the megakernel
+ *                              as before.
  *      "dispatch.coalesce"     1 (default) .. 64: the reference's frame loop as it is -- write sample_index, dispatch, swap the
  *                              two images, once per sample (src/main.cpp:406-416) -- at the speed of "dispatch.samples": the
  *                              context holds back up to that many consecutive "compute" dispatches that continue one

@@ -29,6 +29,10 @@ struct BufferRec {
     ptr::FlatView flat_view{};
     uint32_t flat_nodes = 0, flat_triangles = 0;  // counts from the parsed header
     ptr_handle instances = 0;      // on a flattened-layout buffer: the top level over its placed copies, if any
+    // "bvh.auto_flatten": `flat` was built by the library from the dispatch's own buffers, at these write generations of the
+    // node / index / position buffers (a write to one of them makes the layout stale); or the build failed at them
+    bool flat_is_auto = false, auto_failed = false;
+    uint64_t auto_generations[3] = {};
     bool top_view_valid = false;   // this buffer holds such a top level whose header was parsed
     ptr::InstanceView top_view{};
     uint32_t top_nodes = 0, top_depth = 0;
@@ -107,6 +111,7 @@ struct ptr_ctx {
     // "dispatch.coalesce": consecutive single-sample "compute" dispatches that continue one accumulation chain (same scene,
     // sample_index + 1, the two images swapped) are held back and rendered as ONE dispatch of that many samples
     int opt_coalesce = 1;           // dispatches held back at most (1 = every dispatch runs at once)
+    int opt_auto_flatten = 0;       // 1: a "compute" dispatch with no flattened layout bound builds one on the GPU and binds it
     struct Pending {
         bool active = false;
         uint8_t last[64] = {};      // constant block of the newest dispatch held back
@@ -497,6 +502,51 @@ int validate_scene(ptr_ctx* c, const uint64_t addr[7], const ptr_handle handles[
     return PTR_OK;
 }
 
+// "bvh.auto_flatten": the strict drop-in caller uploads the reference's buffers and nothing else; its "compute" dispatches would
+// walk the reference's threaded tree in the megakernel (hundreds of nodes per ray).  With the option set the library builds the
+// flattened layout itself -- GPU builder over the dispatch's index and position buffers, tie-break ranks taken from the threaded
+// tree so that equal-t hits resolve as the reference's visiting order does -- binds it to the node buffer, and the dispatch takes
+// the wavefront pipeline.  Rebuilt when one of the three buffers is written again.  Returns PTR_OK with *flat_out = 0 when the
+// dispatch does not qualify (buffers not addressed from their start, no full threaded tree, build failed): the megakernel runs.
+int auto_flatten(ptr_ctx* c, const uint64_t addr[7], const ptr_handle handles[7], ptr_handle* flat_out) {
+    *flat_out = 0;
+    const uint64_t gens[3] = { c->buffers[handles[1]].generation, c->buffers[handles[2]].generation, c->buffers[handles[3]].generation };
+    {
+        BufferRec& nb = c->buffers[handles[1]];
+        if (nb.flat && nb.flat_is_auto && !memcmp(nb.auto_generations, gens, sizeof gens)) { *flat_out = nb.flat; return PTR_OK; }
+        if (nb.flat && !nb.flat_is_auto) { *flat_out = nb.flat; return PTR_OK; }
+        if (nb.auto_failed && !memcmp(nb.auto_generations, gens, sizeof gens)) return PTR_OK;
+    }
+    for (int i = 1; i <= 3; i++)
+        if (addr[i] != (uint64_t)(uintptr_t)c->buffers[handles[i]].ptr) return PTR_OK;
+    const uint64_t triangles = c->buffers[handles[2]].size / (4u * (uint64_t)c->opt_index_words);
+    if (triangles == 0 || triangles >= (1u << 29)) return PTR_OK;
+    if (c->buffers[handles[1]].size / sizeof(ptr::ThreadedNode) < 2 * triangles - 1) return PTR_OK;   // no full tree to take the ranks from
+    int rc = drain_frames(c);
+    if (rc) return rc;
+    if (c->buffers[handles[1]].flat_is_auto && c->buffers[handles[1]].flat) {   // the stale layout goes
+        const ptr_handle old = c->buffers[handles[1]].flat;
+        PTR_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+        PTR_HIP_CHECK(c, hipFree(c->buffers[old].ptr));
+        c->buffers[old] = BufferRec();
+        c->buffers[handles[1]].flat = 0;
+    }
+    ptr_handle flat = 0;
+    rc = ptr_bvh_build_flat(c, handles[2], handles[3], (uint32_t)triangles, &flat);
+    if (rc == PTR_OK) rc = ptr_bvh_flat_set_reference_ranks(c, flat, handles[1], (uint32_t)triangles);
+    BufferRec& nb = c->buffers[handles[1]];   // (the buffer table may have grown: look the record up again)
+    memcpy(nb.auto_generations, gens, sizeof gens);
+    if (rc != PTR_OK) {
+        // e.g. a tree deeper than the traversal stack: the dispatch is still answered, by the kernel that needs no layout
+        if (flat) { (void)hipFree(c->buffers[flat].ptr); c->buffers[flat] = BufferRec(); }
+        nb.auto_failed = true; nb.flat_is_auto = false; nb.flat = 0;
+        return PTR_OK;
+    }
+    nb.flat = flat; nb.flat_is_auto = true; nb.auto_failed = false;
+    *flat_out = flat;
+    return PTR_OK;
+}
+
 // no_alloc: the ptr_dispatch_static variant -- the frame runs start to end on the context's stream in this GPU's fixed
 // scratch array, and nothing on the way allocates (no scene check, no record gathering, no streams or events).
 // batch: dispatches that were held back ("dispatch.coalesce"), rendered now as one dispatch of batch->count samples; the
@@ -557,6 +607,10 @@ int dispatch_compute(ptr_ctx* c, const uint8_t constants[64], uint32_t gx, uint3
         sv.prev_image_plus_one = batch->count >= 2u ? k.accumulation_index + 1u : 0u;
     }
 
+    if (c->opt_auto_flatten && force == 0 && !no_alloc && meta.debug_bvh != 1u) {
+        ptr_handle built = 0;
+        if ((rc = auto_flatten(c, k.addr, handles, &built))) return rc;
+    }
     BufferRec* bvh_buf = &c->buffers[handles[1]];
     BufferRec* flat_buf = bvh_buf->flat ? find_buffer(c, bvh_buf->flat) : nullptr;
     bool wavefront = force == 2 || (force == 0 && flat_buf != nullptr);
@@ -1165,7 +1219,13 @@ int ptr_bvh_bind_flat(ptr_ctx* c, ptr_handle threaded_nodes, ptr_handle flat) {
     }
     int rc = enter(c); if (rc) return rc;
     if ((rc = drain_frames(c))) return rc;
+    if (b->flat_is_auto && b->flat && b->flat != flat) {   // the caller's layout replaces the one the library built
+        PTR_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+        PTR_HIP_CHECK(c, hipFree(c->buffers[b->flat].ptr));
+        c->buffers[b->flat] = BufferRec();
+    }
     b->flat = flat;
+    b->flat_is_auto = false;
     return PTR_OK;
 }
 
@@ -1391,6 +1451,11 @@ int ptr_set_option(ptr_ctx* c, const char* key, int value) {
     if (!strcmp(key, "scene.validate")) {
         if (value != 0 && value != 1) return fail(c, PTR_E_INVALID, "scene.validate: 0 or 1");
         c->opt_validate = value;
+        return PTR_OK;
+    }
+    if (!strcmp(key, "bvh.auto_flatten")) {
+        if (value != 0 && value != 1) return fail(c, PTR_E_INVALID, "bvh.auto_flatten: 0 or 1");
+        c->opt_auto_flatten = value;
         return PTR_OK;
     }
     if (!strcmp(key, "dispatch.coalesce")) {

@@ -876,3 +876,53 @@ def test_a_held_back_dispatch_runs_before_anything_else_sees_its_images(ctx):
         want, _, _ = oracle_frames(b, frames, use_flat=True, materials=gs.materials_host, textures=gs.texture_table)
         assert np.array_equal(got[..., :3], np.sqrt(want[..., :3])), frames
     tone.destroy()
+
+
+# ---- "bvh.auto_flatten": the reference's buffers in, the fast pipeline out ----
+def test_dispatch_flattens_the_tree_itself_when_asked_to(ctx):
+    """A strict drop-in caller uploads the reference's seven buffers and binds nothing else.  With "bvh.auto_flatten" its
+    "compute" dispatches build the flattened layout on the GPU (tie ranks from the threaded tree), bind it and take the wavefront
+    pipeline: same image as the megakernel over the reference's tree, which is what the dispatch runs without the option."""
+    from path_tracer_amd import hip
+    b = make_bundle("atrium", 20_000, 96, 64, max_bounce=3)
+    gs = hip.GpuScene(ctx, b, b["nodes"], None, b["meta"])              # no flattened layout uploaded or bound
+
+    def render(spp):
+        loop = hip.FrameLoop(ctx, gs, 96, 64, "compute")
+        ctx.profile_read(reset=True)
+        ctx.profile_enable(True)
+        for _ in range(spp):
+            loop.frame()
+        img = loop.latest().read()
+        ctx.profile_enable(False)
+        ran = {k for k, v in ctx.profile_read(reset=True).items() if v["launches"]}
+        loop.accumulation.destroy(); loop.output.destroy()
+        return img, ran
+
+    plain, ran = render(3)
+    assert "compute.megakernel" in ran and "wavefront.extend" not in ran
+    ctx.set_option("bvh.auto_flatten", 1)
+    try:
+        fast, ran = render(3)
+        assert "wavefront.extend" in ran and "bvh.build_flat" in ran and "compute.megakernel" not in ran
+        assert np.array_equal(fast, plain)
+        again, ran = render(3)                                            # built once: the layout stays bound
+        assert "bvh.build_flat" not in ran and np.array_equal(again, plain)
+
+        # new geometry in the same buffers (the scene mirrored in x: other tree, other image): the layout is rebuilt from it
+        m = dict(b)
+        m["positions"] = np.asarray(b["positions"], np.float32).reshape(-1, 3) * np.array([-1, 1, 1], np.float32)
+        m["triangles"] = np.asarray(b["triangles"], np.float32).reshape(-1, 3, 3) * np.array([-1, 1, 1], np.float32)
+        from path_tracer_amd import host
+        nodes = host.bvh_build(m["triangles"].reshape(-1, 9))
+        assert nodes.nbytes == np.asarray(b["nodes"]).nbytes
+        gs.positions_buffer.write(np.ascontiguousarray(m["positions"], np.float32))
+        gs.bvh_buffer.write(nodes)
+        moved, ran = render(2)
+        assert "bvh.build_flat" in ran and "wavefront.extend" in ran
+    finally:
+        ctx.set_option("bvh.auto_flatten", 0)
+    ctx.bind_flat(gs.bvh_buffer, None)                                    # back to the reference's tree alone
+    want, ran = render(2)
+    assert "compute.megakernel" in ran and np.array_equal(moved, want)
+    assert not np.array_equal(moved, plain[:])
