@@ -60,7 +60,7 @@ def build_scene(args, rank):
         t1 = time.time()
         nodes = np.zeros((1, 8), np.uint32)
         nodes[0, 3] = 0xFFFFFFFF
-        flat = None if getattr(args, "bvh", "host") == "gpu" else host.bvh_flatten(sc["triangles"], None, threads=min(16, os.cpu_count() or 1))
+        flat = None if getattr(args, "bvh", "host") in ("gpu", "auto") else host.bvh_flatten(sc["triangles"], None, threads=min(16, os.cpu_count() or 1))
         if two_level and flat is not None:
             sc["flat_instances"] = host.bvh_flatten_instances(flat, sc["instance_transforms"])
         t3 = time.time()
@@ -79,7 +79,7 @@ def build_scene(args, rank):
         nodes = host.bvh_build(sc["triangles"], host.SAH_PARTITIONED)
         ranks, ref_note = None, "sah_partitioned (reference_order does not terminate)"
     t2 = time.time()
-    flat = host.bvh_flatten(sc["triangles"], ranks, threads=min(16, os.cpu_count() or 1))
+    flat = None if getattr(args, "bvh", "host") == "auto" else host.bvh_flatten(sc["triangles"], ranks, threads=min(16, os.cpu_count() or 1))
     t3 = time.time()
     c = sc["camera"]
     cam = host.camera(c["pos"], c["target"], c["v_fov"], args.width / args.height, c["aperture"], c["focus"])
@@ -212,7 +212,9 @@ def make_parser():
     ap.add_argument("--two-level", action="store_true", help="with --instances: keep ONE copy of the scene and its tree, and place it through a top-level tree")
     ap.add_argument("--pipeline", default="compute", choices=["compute", "compute.megakernel", "compute.wavefront"])
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="budget of the CPU baseline leg (0 = skip)")
-    ap.add_argument("--bvh", default="host", choices=["host", "gpu"], help="host: binned-SAH flattener (default); gpu: ptr_bvh_build_flat")
+    ap.add_argument("--bvh", default="host", choices=["host", "gpu", "auto"],
+                    help="host: binned-SAH flattener (default); gpu: ptr_bvh_build_flat; auto: only the reference's buffers are uploaded and "
+                         "\"bvh.auto_flatten\" lets the first dispatch build and bind the layout")
     ap.add_argument("--stream", default="torch", choices=["torch", "own"], help="the context's stream: torch's current stream or its own")
     ap.add_argument("--frames-in-flight", type=int, default=2, help="consecutive frames overlapped on internal streams (1 = none)")
     ap.add_argument("--partition", default="tiles", choices=["tiles", "samples"], help="how N > 1 GPUs share the work (see the module text)")
@@ -410,6 +412,8 @@ def main():
         ctx = hip.Context(local_rank, stream=stream.cuda_stream if args.stream == "torch" else None)
         for kv in filter(None, os.environ.get("PTR_BENCH_OPTIONS", "").split(",")):   # tuning experiments: "key=value,key=value"
             ctx.set_option(kv.split("=")[0], int(kv.split("=")[1]))
+        if args.bvh == "auto":
+            ctx.set_option("bvh.auto_flatten", 1)
         t_up = time.perf_counter()
         gpu = hip.GpuScene(ctx, sc, nodes, flat, meta)
         ctx.sync()

@@ -4,6 +4,7 @@ set -e
 cd "$GRAFT_REPO_ROOT"
 run() { out=$1; shift; timeout -k 10 500 python3 bench.py --cpu-seconds 0 "$@" 2> gpurun_out/$out.err > gpurun_out/$out.json; echo "$out done"; }
 run line_gpu_bvh --bvh gpu
+run line_auto_flatten --bvh auto
 run line_25M --instances 3x3
 run line_98M --instances 6x6
 run line_98M_gpu_bvh --instances 6x6 --bvh gpu
