@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Randomised parity sweep: random scenes, frame sizes, metadata and dispatch options through the C ABI against the CPU oracle,
-image for image (numpy ==).  What the fixed test cases do not reach by construction -- odd sizes together with partitions,
+image for image (numpy ==).  Kept beside the tests (it checks against the oracle, as they do) but not collected by pytest.  What the fixed test cases do not reach by construction -- odd sizes together with partitions,
 held-back dispatches together with several samples per dispatch, deep bounce counts with the cooperative last-ray walk, ...
-   python scripts/fuzz_parity.py --iterations 200 --seed 1      (on a GPU box; prints one line per case, stops at the first mismatch)"""
+   python tests/fuzz_parity.py --iterations 200 --seed 1      (on a GPU box; prints one line per case, stops at the first mismatch)"""
 import argparse
 import os
 import sys
