@@ -6,6 +6,8 @@
 //                [--dof 0|1] [--downscale D] [--debug-bvh 0|1] [--pipeline compute|compute.megakernel|compute.wavefront]
 //                [--pos x y z] [--target x y z] [--fov deg] [--aperture a] [--focus f] [--out image.pfm|image.ppm|image.png]
 //                [--samples-per-dispatch S]   (1..64: one dispatch renders S consecutive samples, same image, fewer launches)
+//                [--coalesce N]   (the loop stays one dispatch per sample; the library renders N of them at a time)
+//                [--checkpoint FILE [--checkpoint-every N]] [--resume FILE]   (progressive render state: accumulated image + sample count)
 //                [--gpus N [--partition tiles|samples] [--transport rccl|file] [--stripe-rows S] [--rendezvous DIR]]
 //
 // --gpus N (no counterpart in the single-device reference): the process starts N copies of itself, one per GPU, each with
@@ -35,6 +37,30 @@
 
 namespace {
 float clampf(float x, float lo, float hi) { return x < lo ? lo : (x > hi ? hi : x); }
+
+// A checkpoint of a progressive render: "PTRC w h samples\n" + the accumulated RGBA32F image as the next frame reads it.
+// Written to a temporary name first, so that a run killed while writing leaves the previous checkpoint intact.
+void write_checkpoint(const std::string& path, const std::vector<float>& rgba, uint32_t w, uint32_t h, uint32_t samples) {
+    const std::string tmp = path + ".part";
+    FILE* f = std::fopen(tmp.c_str(), "wb");
+    if (!f) throw std::runtime_error("cannot write " + tmp);
+    std::fprintf(f, "PTRC %u %u %u\n", w, h, samples);
+    const bool ok = std::fwrite(rgba.data(), sizeof(float), rgba.size(), f) == rgba.size();
+    if (std::fclose(f) != 0 || !ok || std::rename(tmp.c_str(), path.c_str()) != 0) throw std::runtime_error("cannot write " + path);
+}
+uint32_t read_checkpoint(const std::string& path, std::vector<float>& rgba, uint32_t w, uint32_t h) {
+    FILE* f = std::fopen(path.c_str(), "rb");
+    if (!f) throw std::runtime_error("cannot read " + path);
+    unsigned fw = 0, fh = 0, samples = 0;
+    char tag[8] = {};
+    const bool header = std::fscanf(f, "%4s %u %u %u", tag, &fw, &fh, &samples) == 4 && std::fgetc(f) == '\n' && std::strcmp(tag, "PTRC") == 0;
+    rgba.resize((size_t)w * h * 4);
+    const bool ok = header && fw == w && fh == h && std::fread(rgba.data(), sizeof(float), rgba.size(), f) == rgba.size();
+    std::fclose(f);
+    if (!header) throw std::runtime_error(path + ": not a checkpoint");
+    if (!ok) throw std::runtime_error(path + ": a checkpoint of " + std::to_string(fw) + " x " + std::to_string(fh) + ", the render is " + std::to_string(w) + " x " + std::to_string(h));
+    return samples;
+}
 
 void write_image(const std::string& path, const std::vector<float>& rgba, uint32_t w, uint32_t h) {
     FILE* f = std::fopen(path.c_str(), "wb");
@@ -117,12 +143,15 @@ const char kUsage[] =
     "            --samples-per-dispatch N (1..64 samples per dispatch; same image)   --pipeline compute|compute.megakernel|compute.wavefront\n"
     "            --coalesce N (one dispatch per sample as the reference issues them, rendered N at a time by the library; same image)\n"
     "  camera    --pos X Y Z --target X Y Z --fov DEGREES --aperture A --focus DISTANCE\n"
+    "  progress  --checkpoint FILE [--checkpoint-every N] (the accumulated float image + its sample count, written every N samples and at the end)\n"
+    "            --resume FILE (continue such a render up to --spp samples: same image as an uninterrupted run)\n"
     "  output    --out file.ppm | file.png (8 bits per channel, 256 * clamp(c, 0, 0.999)) | any other name (\"PTRF w h\\n\" + the float RGBA image)\n"
     "  GPUs      --gpus N (one process per GPU is started)   --partition tiles|samples   --stripe-rows N (a multiple of 8)\n"
     "            --transport rccl|file   --rendezvous DIR   [--rank R --device D: set for the started processes]\n";
 
 int main(int argc, char** argv) {
-    std::string scene_path, out_path, pipeline = "compute";
+    std::string scene_path, out_path, pipeline = "compute", checkpoint_path, resume_path;
+    uint32_t checkpoint_every = 0;
     bool apply_transforms = false, gpu_bvh = false, instanced = false;
     uint32_t copies_x = 1, copies_z = 1;
     uint32_t gpus = 1, stripe_rows = 8, samples_per_dispatch = 1, coalesce = 1;
@@ -150,6 +179,9 @@ int main(int argc, char** argv) {
         else if (is("--samples-per-dispatch")) samples_per_dispatch = (uint32_t)std::atoi(next());
         else if (is("--coalesce")) coalesce = (uint32_t)std::atoi(next());
         else if (is("--out")) out_path = next();
+        else if (is("--checkpoint")) checkpoint_path = next();
+        else if (is("--checkpoint-every")) checkpoint_every = (uint32_t)std::atoi(next());
+        else if (is("--resume")) resume_path = next();
         else if (is("--pipeline")) pipeline = next();
         else if (is("--width")) width = (uint32_t)std::atoi(next());
         else if (is("--height")) height = (uint32_t)std::atoi(next());
@@ -175,6 +207,8 @@ int main(int argc, char** argv) {
     if (gpus == 1) rank = 0;
     const bool tiles = partition == "tiles";
     if (gpus > 1 && !tiles && spp % gpus != 0) { std::fprintf(stderr, "--partition samples: --spp must be a multiple of --gpus\n"); return 2; }
+    if (gpus > 1 && !tiles && (!checkpoint_path.empty() || !resume_path.empty())) { std::fprintf(stderr, "--checkpoint / --resume: not with --partition samples (every GPU keeps a mean of its own)\n"); return 2; }
+    if (gpus > 1 && checkpoint_every) { std::fprintf(stderr, "--checkpoint-every: one GPU only (with --gpus N the checkpoint is written once, after the exchange)\n"); return 2; }
     if (device < 0) device = (gpus > 1 && transport == "rccl") ? rank : 0;
 
     try {
@@ -186,7 +220,7 @@ int main(int argc, char** argv) {
             if (tiles) hiprenderer::check(ptr_set_partition(hiprenderer::api, (uint32_t)rank, gpus, stripe_rows), "ptr_set_partition");
             else hiprenderer::check(ptr_set_sample_partition(hiprenderer::api, (uint32_t)rank, gpus), "ptr_set_sample_partition");
         }
-        const uint32_t frames = (gpus > 1 && !tiles) ? spp / gpus : spp;
+        uint32_t frames = (gpus > 1 && !tiles) ? spp / gpus : spp;
         const float aspect_ratio = (float)width / (float)height;
         const auto t_build = std::chrono::steady_clock::now();
         scene main_scene(camera(point3{ pos[0], pos[1], pos[2] }, point3{ target[0], target[1], target[2] }, v_fov, aspect_ratio, aperture, focus), width, height,
@@ -209,6 +243,23 @@ int main(int argc, char** argv) {
         raytracing_pass->set_constant(48, main_scene.materials_buffer);
         raytracing_pass->set_dispatch_size(width / 8 + 1, height / 8 + 1, 1);
 
+        // --resume: the accumulated image of an earlier run and the number of samples in it; this run renders the samples up to --spp
+        uint32_t samples_done = 0;
+        if (!resume_path.empty()) {
+            std::vector<float> rgba;
+            samples_done = read_checkpoint(resume_path, rgba, width, height);
+            if (samples_done > frames) throw std::runtime_error("--resume: the checkpoint already holds " + std::to_string(samples_done) + " samples");
+            accumulation_texture->update(rgba.data());
+            main_scene.meta.sample_index = samples_done + 1;
+            frames -= samples_done;
+        }
+        auto checkpoint = [&](uint32_t samples) {   // after the swap the image written last is `accumulation_texture`
+            std::vector<float> rgba((size_t)width * height * 4);
+            accumulation_texture->read(rgba.data());
+            write_checkpoint(checkpoint_path, rgba, width, height, samples);
+        };
+        uint32_t since_checkpoint = 0;
+
         const auto t0 = std::chrono::steady_clock::now();
         if (samples_per_dispatch == 0 || samples_per_dispatch > 64) throw std::runtime_error("--samples-per-dispatch: 1..64");
         if (coalesce == 0 || coalesce > 64) throw std::runtime_error("--coalesce: 1..64");
@@ -228,6 +279,11 @@ int main(int argc, char** argv) {
             frame += batch;
             std::swap(output_texture, accumulation_texture);
             renderer.finish_frame();
+            since_checkpoint += batch;
+            if (checkpoint_every && !checkpoint_path.empty() && since_checkpoint >= checkpoint_every && frame < frames) {
+                checkpoint(samples_done + frame);
+                since_checkpoint = 0;
+            }
         }
         hiprenderer::check(ptr_set_option(hiprenderer::api, "dispatch.samples", 1), "ptr_set_option");
         hiprenderer::check(ptr_set_option(hiprenderer::api, "dispatch.coalesce", 1), "ptr_set_option");   // runs what is still held back
@@ -260,6 +316,7 @@ int main(int argc, char** argv) {
                      exchange ? (" [rank " + std::to_string(rank) + " of " + std::to_string(gpus) + ", " + partition + " over " + exchange->transport() + "]").c_str() : "",
                      main_scene.triangle_count, main_scene.copy_count, main_scene.bvh_mode.c_str(), build_s, frames, width, height, render_s, render_s * 1e3 / (frames ? frames : 1));
 
+        if (!checkpoint_path.empty() && rank == 0) checkpoint(samples_done + frames);
         if (!out_path.empty() && rank == 0) {
             std::vector<float> rgba((size_t)width * height * 4);
             accumulation_texture->read(rgba.data());  // after the swap the last written image is `accumulation_texture`

@@ -163,6 +163,34 @@ def test_headless_reference_loop_with_held_back_dispatches(tmp_path, extra):
     assert np.array_equal(read_ptrf(out_file), ref)
 
 
+@pytest.mark.parametrize("extra", [(), ("--gpus", "2", "--transport", "file", "--partition", "tiles")])
+def test_headless_checkpoint_and_resume(tmp_path, extra):
+    """--checkpoint / --resume: three samples, stop, four more from the checkpoint (written every two samples on the way when one
+    GPU renders): the image of seven uninterrupted samples, and the last checkpoint holds that image and its sample count."""
+    W, H = 72, 40
+    b = make_bundle("atrium", 3000, W, H, max_bounce=4)
+    scene_file = str(tmp_path / "scene.ptrscene")
+    first, second, out_file = str(tmp_path / "first.ptrc"), str(tmp_path / "second.ptrc"), str(tmp_path / "out.pfm")
+    scenes.save_ptrscene(b, scene_file)
+    r = subprocess.run(headless_cmd(b, scene_file, str(tmp_path / "unused.pfm"), W, H, 3, "--checkpoint", first, *extra), capture_output=True, text=True, timeout=180)
+    assert r.returncode == 0, r.stderr
+    every = () if extra else ("--checkpoint-every", "2")
+    r = subprocess.run(headless_cmd(b, scene_file, out_file, W, H, 7, "--resume", first, "--checkpoint", second, *every, *extra),
+                       capture_output=True, text=True, timeout=180)
+    assert r.returncode == 0, r.stderr
+    ref, _, _ = oracle_frames(b, 7, use_flat=True)
+    assert np.array_equal(read_ptrf(out_file), ref)
+    with open(second, "rb") as f:
+        tag, w, h, samples = f.readline().split()
+        assert (tag, int(w), int(h), int(samples)) == (b"PTRC", W, H, 7)
+        assert np.array_equal(np.frombuffer(f.read(), np.float32).reshape(H, W, 4), ref)
+    # a checkpoint of another frame size, or one that is already past --spp, is refused
+    r = subprocess.run(headless_cmd(b, scene_file, out_file, W + 8, H, 9, "--resume", second), capture_output=True, text=True, timeout=180)
+    assert r.returncode != 0 and "checkpoint of" in r.stderr
+    r = subprocess.run(headless_cmd(b, scene_file, out_file, W, H, 5, "--resume", second), capture_output=True, text=True, timeout=180)
+    assert r.returncode != 0 and "already holds" in r.stderr
+
+
 @pytest.mark.parametrize("ranks,transport", [(2, "file"), (3, "file"), (1, "rccl")])
 def test_headless_tile_partition_over_processes(tmp_path, ranks, transport):
     """--gpus N --partition tiles: N processes (here all on the one GPU, exchanging through the file transport -- RCCL refuses
