@@ -551,6 +551,10 @@ def main():
         for _ in range(3):
             loop.latest().read()
         build_times["frame_readback_ms"] = (time.perf_counter() - t_rb) / 3 * 1e3
+        t_rb = time.perf_counter()
+        for _ in range(3):
+            loop.latest().read_unorm8()       # ... and when it shows them: 8 bits per channel, converted on the device
+        build_times["frame_readback_unorm8_ms"] = (time.perf_counter() - t_rb) / 3 * 1e3
 
         # the same K steps the way the reference's frame loop issues them: one dispatch per sample
         single_ms = None

@@ -71,6 +71,11 @@ int ptr_image_wrap(ptr_ctx* ctx, void* device_memory, uint32_t width, uint32_t h
 int ptr_image_destroy(ptr_ctx* ctx, ptr_handle image);
 int ptr_image_upload(ptr_ctx* ctx, ptr_handle image, const void* texels);  /* whole image, host memory */
 int ptr_image_read(ptr_ctx* ctx, ptr_handle image, void* texels);          /* whole image, host memory */
+/* The texels a present would show, width * height RGBA8 words (R in the low byte): the reference blits the RGBA32F output image
+ * to the swapchain's 8-bit UNORM image every frame (vkapi::blit_full, src/vk-api.cpp:1194-1224, called at
+ * src/vk-renderer.cpp:199); the conversion is the API's float -> UNORM rule -- NaN 0, clamp to [0, 1], x 255, round to nearest --
+ * and runs on the device, so a caller that shows every frame moves a quarter of the bytes ptr_image_read moves. */
+int ptr_image_read_unorm8(ptr_ctx* ctx, ptr_handle image, void* rgba8);
 int ptr_image_index(ptr_ctx* ctx, ptr_handle image, uint32_t* bindless_index);
 int ptr_sampler_index(ptr_ctx* ctx, ptr_handle sampler, uint32_t* bindless_index);
 int ptr_image_address(ptr_ctx* ctx, ptr_handle image, uint64_t* device_address);

@@ -147,6 +147,8 @@ struct ptr_ctx {
     volatile uint32_t* fault = nullptr;
     uint32_t* fault_device = nullptr;
     ptr::WavefrontScratch static_scratch{};   // views into this GPU's fixed scratch array (ptr_dispatch_static)
+    void* unorm8_stage = nullptr;             // ptr_image_read_unorm8: the converted texels on the device, grown on demand
+    size_t unorm8_stage_bytes = 0;
 };
 
 namespace {
@@ -942,6 +944,7 @@ int ptr_ctx_destroy(ptr_ctx* c) {
     for (auto& im : c->images) if (im.alive && im.owned && im.ptr) (void)hipFree(im.ptr);
     for (auto& im : c->images) if (im.alive && im.tiled) (void)hipFree(im.tiled);
     if (c->shade_records) (void)hipFree(c->shade_records);
+    if (c->unorm8_stage) (void)hipFree(c->unorm8_stage);
     if (c->d_validate) (void)hipFree(c->d_validate);
     if (c->d_images) (void)hipFree(c->d_images);
     if (c->d_stats) (void)hipFree(c->d_stats);
@@ -1155,6 +1158,28 @@ int ptr_image_read(ptr_ctx* c, ptr_handle h, void* texels) {
     if (!texels) return fail(c, PTR_E_INVALID, "ptr_image_read: null texels");
     int rc = enter(c); if (rc) return rc;
     PTR_HIP_CHECK(c, hipMemcpyAsync(texels, im->ptr, (size_t)im->w * im->h * texel_size(im->format), hipMemcpyDeviceToHost, c->stream));
+    PTR_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+    return take_fault(c);
+}
+
+int ptr_image_read_unorm8(ptr_ctx* c, ptr_handle h, void* rgba8) {
+    if (!c) return PTR_E_INVALID;
+    ImageRec* im = find_image(c, h);
+    if (!im) return fail(c, PTR_E_INVALID, "ptr_image_read_unorm8: unknown image %u", h);
+    if (!rgba8) return fail(c, PTR_E_INVALID, "ptr_image_read_unorm8: null destination");
+    if (im->format != PTR_FORMAT_RGBA32_SFLOAT) return fail(c, PTR_E_UNSUPPORTED, "ptr_image_read_unorm8: the image must be RGBA32_SFLOAT");
+    int rc = enter(c); if (rc) return rc;
+    const size_t bytes = (size_t)im->w * im->h * 4;
+    if (bytes == 0) return PTR_OK;
+    if (bytes > c->unorm8_stage_bytes) {
+        PTR_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+        if (c->unorm8_stage) PTR_HIP_CHECK(c, hipFree(c->unorm8_stage));
+        c->unorm8_stage = nullptr; c->unorm8_stage_bytes = 0;
+        PTR_HIP_CHECK(c, hipMalloc(&c->unorm8_stage, bytes));
+        c->unorm8_stage_bytes = bytes;
+    }
+    PTR_HIP_CHECK(c, ptr::launch_unorm8_pack(c->stream, im->ptr, im->w * im->h, c->unorm8_stage));
+    PTR_HIP_CHECK(c, hipMemcpyAsync(rgba8, c->unorm8_stage, bytes, hipMemcpyDeviceToHost, c->stream));
     PTR_HIP_CHECK(c, hipStreamSynchronize(c->stream));
     return take_fault(c);
 }

@@ -66,6 +66,8 @@ hipError_t launch_linearize_resolve(hipStream_t s, const ImageDesc* images, uint
 
 // Fills the 4 x 4-tiled copy of a row-major RGBA8 image (ceil(width / 4) * ceil(height / 4) * 64 bytes).
 hipError_t launch_tile_rgba8(hipStream_t s, const void* linear, void* tiled, uint32_t width, uint32_t height);
+// RGBA32F texels -> RGBA8 UNORM words (clamp, x 255, round to nearest): the conversion of the reference's present blit.
+hipError_t launch_unorm8_pack(hipStream_t s, const void* image, uint32_t texels, void* packed);
 
 // Tile-partition exchange: copies between the rows of an RGBA32F frame and the packed chunks an all-gather moves.
 // pack (unpack = false): ranks = 1, first_rank = the owner; unpack: first_rank = 0, ranks = world.

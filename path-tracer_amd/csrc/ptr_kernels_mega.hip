@@ -158,6 +158,29 @@ hipError_t launch_tile_rgba8(hipStream_t s, const void* linear, void* tiled, uin
     return hipGetLastError();
 }
 
+// What a present shows: the reference blits the RGBA32F output image to the swapchain's 8-bit UNORM image
+// (vkapi::blit_full, src/vk-api.cpp:1194-1224; src/vk-renderer.cpp:199).  Float to UNORM as the API defines it: NaN gives 0, the
+// value is clamped to [0, 1], scaled by 255 and rounded to the nearest integer.  One texel per lane, R in the low byte.
+__global__ __launch_bounds__(256) void ptr_unorm8_pack(const float4* image, uint32_t texels, uint32_t* packed) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= texels) return;
+    const float4 c = image[i];
+    const float v[4] = { c.x, c.y, c.z, c.w };
+    uint32_t word = 0u;
+    for (int k = 0; k < 4; k++) {
+        float f = v[k];
+        f = f == f ? f : 0.0f;
+        f = f < 0.0f ? 0.0f : (f > 1.0f ? 1.0f : f);
+        word |= (uint32_t)rintf(f * 255.0f) << (8 * k);
+    }
+    packed[i] = word;
+}
+hipError_t launch_unorm8_pack(hipStream_t s, const void* image, uint32_t texels, void* packed) {
+    if (texels == 0u) return hipSuccess;
+    hipLaunchKernelGGL(ptr_unorm8_pack, dim3((texels + 255u) / 256u), dim3(256), 0, s, (const float4*)image, texels, (uint32_t*)packed);
+    return hipGetLastError();
+}
+
 // Tile-partition exchange helpers (no counterpart in the single-GPU reference).  A frame of `height` rows is cut into
 // stripes of `stripe_rows` rows; rank r of `world` owns the stripes s with s % world == r.  pack: the owned stripes of one
 // rank, in order, as one contiguous chunk (`chunk_stripes` stripes, rows past the frame's end zero) -- what an all-gather

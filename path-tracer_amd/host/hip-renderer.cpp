@@ -58,6 +58,7 @@ Texture::Texture(size_t w, size_t h, size_t d, int fmt, Sampler* texture_sampler
 Texture::~Texture() { if (hiprenderer::api && device_image) ptr_image_destroy(hiprenderer::api, device_image); }
 void Texture::update(const void* new_data) { hiprenderer::check(ptr_image_upload(hiprenderer::api, device_image, new_data), "ptr_image_upload"); }
 void Texture::read(void* dst) const { hiprenderer::check(ptr_image_read(hiprenderer::api, device_image, dst), "ptr_image_read"); }
+void Texture::read_unorm8(void* dst) const { hiprenderer::check(ptr_image_read_unorm8(hiprenderer::api, device_image, dst), "ptr_image_read_unorm8"); }
 uint32_t Texture::bindless_index() const {
     uint32_t i = 0;
     hiprenderer::check(ptr_image_index(hiprenderer::api, device_image, &i), "ptr_image_index");

@@ -47,6 +47,8 @@ public:
     // Ownership of `new_data` stays with the caller.
     void update(const void* new_data);
     void read(void* dst) const;
+    // width*height RGBA8 words: what the reference's present blit shows of an RGBA32F image (vkapi::blit_full, src/vk-api.cpp:1194-1224)
+    void read_unorm8(void* dst) const;
     size_t size() const { return width * height * depth * pixel_size(format); }
     static size_t pixel_size(int format) { return format == PTR_FORMAT_RGBA8_UNORM ? 4 : (format == PTR_FORMAT_RGBA32_SFLOAT ? 16 : 0); }
     uint32_t bindless_index() const;

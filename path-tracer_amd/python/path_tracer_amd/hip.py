@@ -56,6 +56,7 @@ def lib():
         "ptr_image_destroy": [vp, u32],
         "ptr_image_upload": [vp, u32, vp],
         "ptr_image_read": [vp, u32, vp],
+        "ptr_image_read_unorm8": [vp, u32, vp],
         "ptr_image_index": [vp, u32, P(u32)],
         "ptr_sampler_index": [vp, u32, P(u32)],
         "ptr_image_address": [vp, u32, P(u64)],
@@ -90,7 +91,7 @@ def lib():
 
 ABI_SYMBOLS = ["ptr_ctx_create", "ptr_ctx_destroy", "ptr_ctx_set_stream", "ptr_last_error", "ptr_sync", "ptr_flush", "ptr_buffer_create",
                "ptr_buffer_destroy", "ptr_buffer_write", "ptr_buffer_read", "ptr_buffer_address", "ptr_sampler_create",
-               "ptr_image_create", "ptr_image_wrap", "ptr_image_destroy", "ptr_image_upload", "ptr_image_read",
+               "ptr_image_create", "ptr_image_wrap", "ptr_image_destroy", "ptr_image_upload", "ptr_image_read", "ptr_image_read_unorm8",
                "ptr_image_index", "ptr_sampler_index", "ptr_image_address", "ptr_bvh_bind_flat", "ptr_bvh_bind_instances", "ptr_dispatch", "ptr_dispatch_static",
                "ptr_set_partition", "ptr_image_pack_stripes", "ptr_image_unpack_stripes", "ptr_set_sample_partition", "ptr_set_option", "ptr_set_capture", "ptr_stats_enable", "ptr_stats_read", "ptr_profile_enable",
                "ptr_profile_read", "ptr_profile_names", "ptr_device_function", "ptr_bvh_build_flat", "ptr_bvh_flat_set_reference_ranks"]
@@ -299,6 +300,12 @@ class Texture:
         else:
             out = np.empty((self.height, self.width, 4), dtype=np.uint8)
         self.ctx._check(self.ctx._L.ptr_image_read(self.ctx.handle, self.handle, out.ctypes.data))
+        return out
+
+    def read_unorm8(self):
+        """The image as a present shows it: (height, width, 4) uint8, converted on the device (ptr_image_read_unorm8)."""
+        out = np.empty((self.height, self.width, 4), dtype=np.uint8)
+        self.ctx._check(self.ctx._L.ptr_image_read_unorm8(self.ctx.handle, self.handle, out.ctypes.data))
         return out
 
     def destroy(self):

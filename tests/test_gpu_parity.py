@@ -926,3 +926,26 @@ def test_dispatch_flattens_the_tree_itself_when_asked_to(ctx):
     want, ran = render(2)
     assert "compute.megakernel" in ran and np.array_equal(moved, want)
     assert not np.array_equal(moved, plain[:])
+
+
+def test_present_style_readback_converts_on_the_device(ctx):
+    """ptr_image_read_unorm8: float -> 8-bit UNORM as the reference's present blit converts (NaN 0, clamp, x 255, round to nearest)."""
+    from path_tracer_amd import hip
+    rng = np.random.default_rng(11)
+    W, H = 77, 45
+    img = rng.uniform(-0.25, 1.25, size=(H, W, 4)).astype(np.float32)
+    img[0, 0] = [np.nan, np.inf, -np.inf, 0.5]
+    img[0, 1] = [0.0, 1.0, 0.5 / 255.0, 1.5 / 255.0]               # the two ties round to even: 0 and 2
+    img[0, 2] = np.float32(254.5 / 255.0)
+    t = ctx.create_2d_texture(W, H, hip.FORMAT_RGBA32_SFLOAT)
+    t.update(img)
+    got = t.read_unorm8()
+    clean = np.where(np.isnan(img), np.float32(0), img)
+    want = np.rint(np.clip(clean, np.float32(0), np.float32(1)) * np.float32(255.0)).astype(np.uint8)
+    assert np.array_equal(got, want)
+    assert got[0, 0].tolist() == [0, 255, 0, 128] and got[0, 1].tolist()[:2] == [0, 255]
+    small = ctx.create_2d_texture(8, 8, hip.FORMAT_RGBA8_UNORM)
+    with pytest.raises(hip.HipError, match="RGBA32_SFLOAT"):
+        small.read_unorm8()
+    for x in (t, small):
+        x.destroy()
