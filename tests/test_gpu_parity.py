@@ -908,6 +908,10 @@ def test_dispatch_flattens_the_tree_itself_when_asked_to(ctx):
         assert np.array_equal(fast, plain)
         again, ran = render(3)                                            # built once: the layout stays bound
         assert "bvh.build_flat" not in ran and np.array_equal(again, plain)
+        ctx.set_option("dispatch.coalesce", 2)                            # with held-back dispatches on top: 3 = 2 + 1
+        both, ran = render(3)
+        ctx.set_option("dispatch.coalesce", 1)
+        assert "wavefront.extend" in ran and np.array_equal(both, plain)
 
         # new geometry in the same buffers (the scene mirrored in x: other tree, other image): the layout is rebuilt from it
         m = dict(b)
