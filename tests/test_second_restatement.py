@@ -256,7 +256,7 @@ import pytest
 
 
 @pytest.mark.parametrize("kind,target,W,H,BOUNCES,min_bounce,dof", [("tiny", 0, 40, 24, 4, 1, 0), ("tiny", 0, 36, 20, 6, 0, 1),
-                                                                     ("atrium", 1500, 32, 18, 3, 1, 0), ("street_exterior", 3000, 30, 18, 5, 2, 0),
+                                                                     ("atrium", 1500, 32, 18, 3, 1, 0), ("street_exterior", 3000, 40, 25, 3, 2, 0),
                                                                      ("street_exterior", 2000, 28, 16, 4, 0, 1)])
 def test_oracle_agrees_with_a_float64_brute_force_restatement_of_the_glsl(kind, target, W, H, BOUNCES, min_bounce, dof):
     b = make_bundle(kind, target, W, H, max_bounce=BOUNCES, min_bounce=min_bounce, enable_dof=dof)
