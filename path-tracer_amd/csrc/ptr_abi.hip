@@ -838,7 +838,7 @@ int dispatch_or_hold(ptr_ctx* c, const uint8_t constants[64], uint32_t gx, uint3
     bool can = c->opt_coalesce > 1 && c->opt_dispatch_samples == 1 && !c->stats_on && !c->capture && force != 1 &&
                read_meta(c, k.addr[0], &meta) == PTR_OK && meta.debug_bvh != 1u && meta.sample_index != 0u;
     for (int i = 0; can && i < 7; i++) can = buffer_at(c, k.addr[i], 1, &handles[i]) != nullptr;
-    if (can && force == 0 && !c->buffers[handles[1]].flat) can = false;   // no flattened layout bound: the megakernel's frame
+    if (can && !c->buffers[handles[1]].flat) can = false;   // no flattened layout bound: the megakernel's frame, or an error to report now
     // a dispatch that names no usable image fails now, not when it would have run
     if (can && (check_storage_image(c, k.output_index, "output") || check_storage_image(c, k.accumulation_index, "accumulation"))) can = false;
     if (!can) {

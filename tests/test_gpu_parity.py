@@ -846,6 +846,20 @@ def test_coalescing_stops_where_the_chain_breaks(ctx):
         assert np.array_equal(want, got)
 
 
+def test_a_dispatch_that_cannot_run_is_refused_at_once_also_when_dispatches_are_held_back(ctx):
+    from path_tracer_amd import hip
+    b = make_bundle("tiny", 0, 32, 24, max_bounce=2)
+    gs = hip.GpuScene(ctx, b, b["nodes"], None, b["meta"])               # no flattened layout bound
+    loop = hip.FrameLoop(ctx, gs, 32, 24, "compute.wavefront")
+    ctx.set_option("dispatch.coalesce", 8)
+    try:
+        with pytest.raises(hip.HipError, match="no flattened layout"):
+            loop.frame()                                                  # reported by the dispatch itself, not by a later call
+        ctx.sync()                                                        # nothing was left behind
+    finally:
+        ctx.set_option("dispatch.coalesce", 1)
+
+
 def test_a_held_back_dispatch_runs_before_anything_else_sees_its_images(ctx):
     from path_tracer_amd import hip
     b = make_bundle("atrium", 20_000, 64, 48, max_bounce=2)
