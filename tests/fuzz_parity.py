@@ -48,13 +48,18 @@ def main():
         spp = int(rng.integers(1, 8))
         per = int(rng.integers(1, 5))
         hold = int(rng.choice([1, 1, 2, 3, 8]))
+        # now and then the strict drop-in kernel over the reference's own tree (one sample per dispatch, nothing held back),
+        # against the oracle's walk of that tree
+        mega = tree == "host" and rng.random() < 0.2
+        if mega:
+            per, hold = 1, 1
         in_flight = int(rng.choice([1, 2, 2, 3]))
         world = int(rng.choice([1, 1, 2, 3]))
         rank = int(rng.integers(0, world))
         stripe = int(rng.choice([8, 16, 24]))
         refill = int(rng.choice([8, 16, 32, 64]))
         alone = int(rng.choice([0, 0, 3, 1000]))
-        what = (f"{kind}/{tree} {b['triangles'].shape[0]} tris {W}x{H} {meta_kw} spp {spp} per-dispatch {per} hold {hold} in-flight {in_flight} "
+        what = (f"{kind}/{'mega' if mega else tree} {b['triangles'].shape[0]} tris {W}x{H} {meta_kw} spp {spp} per-dispatch {per} hold {hold} in-flight {in_flight} "
                 f"rank {rank}/{world} stripe {stripe} refill {refill} alone {alone}")
         gs = hip.GpuScene(ctx, b, b["nodes"], b["flat"], b["meta"])
         if tree == "gpu":         # the layout built on the GPU from the uploaded buffers; the oracle walks that very blob
@@ -67,14 +72,14 @@ def main():
         ctx.set_option("dispatch.coalesce", hold)
         ctx.set_partition(rank, world, stripe)
         # downscaled frames write blocks: the image is as large as the blocks reach
-        loop = hip.FrameLoop(ctx, gs, W, H, "compute", samples_per_dispatch=per)
+        loop = hip.FrameLoop(ctx, gs, W, H, "compute.megakernel" if mega else "compute", samples_per_dispatch=per)
         try:
             loop.frames(spp)
             img = loop.latest().read()
         finally:
             ctx.set_option("dispatch.coalesce", 1)
             ctx.set_partition(0, 1, 8)
-        ref, counters, _ = oracle_frames(b, spp, use_flat=True, materials=gs.materials_host, textures=gs.texture_table)
+        ref, counters, _ = oracle_frames(b, spp, use_flat=not mega, materials=gs.materials_host, textures=gs.texture_table)
         d = meta_kw.get("downscale_factor", 1)
         # a rank owns rows of the DISPATCH domain (frame rows / downscale); its image rows follow from the block size
         owned = np.zeros(H, bool)
