@@ -165,6 +165,13 @@ int ptr_set_sample_partition(ptr_ctx* ctx, uint32_t rank, uint32_t world);
  *                              lanes finish it together, one pending node or leaf per lane (default 0; 1000000 = never)
  *      "build.traversal_cost"  ptr_bvh_build_flat: cost of entering a node in percent of one triangle test (default 100); a
  *                              subtree of up to 4 triangles becomes one leaf when that is cheaper by the surface-area heuristic
+ *      "build.cluster_radius"  ptr_bvh_build_flat: 0 = the binary tree comes from the common prefixes of the triangles' Morton
+ *                              keys (radix tree); 1..64 = from locally-ordered clustering: every round each cluster merges with
+ *                              the neighbour, at most that many places away in Morton order, with which it makes the smallest
+ *                              box, where the choice is mutual.  Default 4: 4-7 % fewer node visits per ray than the radix tree on
+ *                              street, interior and atrium scenes for a tenth more build time (2 % more on a regular grid of
+ *                              copies of a scene, which the Morton cells already cut exactly); larger radii build worse trees
+ *                              on all of them.  Either way the layout is the same and images are those of the oracle.
  *      "extend.leaf_all"       1 (default): a leaf turn tests the lane's whole leaf; 0: one triangle per turn
  *      "extend.leaf_weight"    1, 2 (default), 4: how strongly lanes waiting at a leaf outvote lanes waiting at an
  *                              inner node when the wave picks the step kind of its next iteration

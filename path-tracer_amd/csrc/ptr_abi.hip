@@ -101,6 +101,7 @@ struct ptr_ctx {
     int opt_extend_inner_reps = 3;  // inner-node steps per inner turn
     int opt_extend_alone_turns = 0;  // turns a wave's last ray walks alone before the wave finishes it together
     int opt_build_traversal_cost = 100;  // GPU tree build: cost of entering a node, in percent of one triangle test
+    int opt_build_cluster_radius = 4;    // GPU tree build: 0 = radix tree over the Morton keys, > 0 = locally-ordered clustering with this search radius
     int opt_extend_leaf_all = 1;    // 1: a leaf turn tests every triangle of the leaf, 0: one triangle per turn
     int opt_extend_leaf_weight = 2; // leaf lanes count this many times when a traversal wave picks its next step kind
     int opt_extend_refill = 16;     // idle lanes that trigger a refill of the traversal wave (8, 16, 32, 48, 64)
@@ -1293,7 +1294,11 @@ int ptr_bvh_build_flat(ptr_ctx* c, ptr_handle indices, ptr_handle positions, uin
     int status = 0;
     hipEvent_t t0 = nullptr, t1 = nullptr;
     if (c->profile_on) { t0 = take_event(c); t1 = take_event(c); if (t0) (void)hipEventRecord(t0, c->stream); }
-    const hipError_t e = ptr::build_flat_bvh(c->stream, sv, triangle_count, (uint32_t)(vertices > 0xffffffffull ? 0xffffffffull : vertices), b.ptr, bytes, (float)c->opt_build_traversal_cost * 0.01f, &status);
+    const uint32_t vertex_count = (uint32_t)(vertices > 0xffffffffull ? 0xffffffffull : vertices);
+    hipError_t e = ptr::build_flat_bvh(c->stream, sv, triangle_count, vertex_count, b.ptr, bytes, (float)c->opt_build_traversal_cost * 0.01f, c->opt_build_cluster_radius, &status);
+    // clustering that does not finish within its round limit (boxes that each prefer the next one along a long chain): the radix tree always finishes
+    if (e == hipSuccess && status == -6)
+        e = ptr::build_flat_bvh(c->stream, sv, triangle_count, vertex_count, b.ptr, bytes, (float)c->opt_build_traversal_cost * 0.01f, 0, &status);
     if (c->profile_on && t0 && t1) { (void)hipEventRecord(t1, c->stream); c->profile["bvh.build_flat"].pending.emplace_back(t0, t1); }
     if (e != hipSuccess || status != 0) {
         (void)hipFree(b.ptr);
@@ -1444,6 +1449,11 @@ int ptr_set_option(ptr_ctx* c, const char* key, int value) {
     if (!strcmp(key, "build.traversal_cost")) {
         if (value < 0 || value > 10000) return fail(c, PTR_E_INVALID, "build.traversal_cost: 0..10000 (percent of a triangle test)");
         c->opt_build_traversal_cost = value;
+        return PTR_OK;
+    }
+    if (!strcmp(key, "build.cluster_radius")) {
+        if (value < 0 || value > 64) return fail(c, PTR_E_INVALID, "build.cluster_radius: 0 (radix tree) or 1..64");
+        c->opt_build_cluster_radius = value;
         return PTR_OK;
     }
     if (!strcmp(key, "extend.inner_reps")) {

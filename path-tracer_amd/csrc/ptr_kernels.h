@@ -90,7 +90,10 @@ hipError_t launch_wf_accumulate(hipStream_t s, const SceneView& sv, const Wavefr
 // (-1 bad arguments, -3 node capacity or quantisation, -5 deeper than the traversal stack, others internal).
 size_t flat_build_blob_bytes(uint32_t triangle_count);
 // traversal_cost: cost of entering a node relative to one triangle test, for the leaf decision (surface-area heuristic).
-hipError_t build_flat_bvh(hipStream_t s, const SceneView& sv, uint32_t triangle_count, uint32_t vertex_count, void* blob, size_t blob_bytes, float traversal_cost, int* status);
+// cluster_radius: 0 = binary tree from the Morton keys' prefixes (radix tree); > 0 = from locally-ordered clustering with
+// that search radius (status -6: the clustering did not finish within its round limit).
+hipError_t build_flat_bvh(hipStream_t s, const SceneView& sv, uint32_t triangle_count, uint32_t vertex_count, void* blob, size_t blob_bytes, float traversal_cost,
+                          int cluster_radius, int* status);
 
 // Writes into the triangle records of a flattened layout the ranks of the reference's visiting order: the position of each
 // primitive's leaf among the leaves of the threaded node array (include/bvh.hpp:17-22).  Primitives the array does not hold

@@ -1,17 +1,21 @@
 // GPU construction of the flattened 4-wide BVH (the layout of host/bvh.hpp, version 2) straight from the scene's
-// device buffers: Morton order -> radix tree (Karras 2012) -> bottom-up boxes -> top-down collapse to 4-wide nodes
-// with quantised child boxes.  It trades tree quality for build time (milliseconds instead of a second per few
-// million triangles on the host's binned-SAH builder); the traversal kernels cannot tell the two apart.
+// device buffers: Morton order -> binary tree (locally-ordered clustering, or the radix tree of Karras 2012) -> bottom-up
+// boxes -> top-down collapse to 4-wide nodes with quantised child boxes.  It trades tree quality for build time
+// (milliseconds instead of a second per few million triangles on the host's binned-SAH builder); the traversal kernels
+// cannot tell the two apart.
 //
 //   1. per triangle: box and centroid; scene box by block reduction + ordered-integer atomics
 //   2. 63-bit Morton key of the centroid (21 bits per axis), radix sort of (key, triangle) pairs (hipCUB)
-//   3. binary radix tree over the sorted keys, ties broken by position; parents recorded
+//   3. binary tree: clusters of neighbours in Morton order merged round by round (3b below; the triangles are then put in
+//      the tree's depth-first order), or the radix tree over the sorted keys, ties broken by position; parents recorded
 //   4. boxes bottom-up: the second thread to reach a node merges its children and goes on
 //   5. leaves: a subtree of at most 4 triangles becomes one leaf when that is cheaper, by the surface-area heuristic,
 //      than entering its two children (evaluated bottom-up together with the boxes; the triangles of a subtree are
-//      contiguous in sorted order, so triangle records are simply written in sorted order); wide nodes level by level from the root: a node adopts its two children and keeps replacing
-//      the inner child of largest surface area by that child's children until it has four
-//   6. the wide nodes are put in the order of the radix-tree nodes they grew from (Morton order, deterministic)
+//      neighbours in the triangle order, so the records are simply written in that order); wide nodes level by level from
+//      the root: a node adopts its two children and keeps replacing the inner child of largest surface area by that
+//      child's children until it has four
+//   6. the wide nodes are put in the order of the binary nodes they grew from (deterministic: along the Morton curve for the
+//      radix tree; the top of the tree first and each clustering round along the curve for the clustered one)
 #pragma clang fp contract(off)
 
 #include <hipcub/hipcub.hpp>
@@ -26,6 +30,7 @@ namespace {
 
 constexpr int32_t kEmptyChildRef = INT32_MIN;
 constexpr uint32_t kLeafMax = 4;
+constexpr uint32_t kClusterRoundsMax = 2048;  // clustering rounds before the build gives up (a round merges at least one pair; real scenes need tens)
 
 struct BuildNode {      // one internal node of the binary radix tree
     int32_t left, right;       // >= 0: internal node, < 0: ~sorted position of a single triangle
@@ -141,6 +146,134 @@ __global__ __launch_bounds__(256) void build_tree(uint32_t n, const uint64_t* ke
     if (last == gamma + 1) { nd.right = ~(int32_t)(gamma + 1); leaf_parent[gamma + 1] = (int32_t)i; }
     else { nd.right = (int32_t)(gamma + 1); node_parent[gamma + 1] = (int32_t)i; }
     if (i == 0) node_parent[0] = -1;
+}
+
+// ---- 3b. the binary tree by clustering instead of by key prefixes ---------------------------------------------
+// Parallel locally-ordered clustering (Meister & Bittner 2018): the triangles start as one cluster each, in Morton order.
+// Every round each cluster looks `radius` places to either side for the neighbour whose union with it has the smallest
+// surface area; two clusters that choose each other merge into a node, which takes the place of the lower one; the array
+// is compacted and the next round starts.  The tree follows the geometry instead of the bits of the keys: fewer node
+// visits per ray than the radix tree for a few more milliseconds of build.
+// The choice is made under a strict order of the candidate pairs that both ends agree on -- (area, distance in the array,
+// a parity bit that differs between a cluster's two neighbours at one distance) -- so the pair that is smallest in the whole
+// array always chooses each other: every round merges at least one pair, and equal boxes pair up instead of all choosing
+// the same neighbour.
+PTR_DEV float union_area(const float4 alo, const float4 ahi, const float4 blo, const float4 bhi) {
+    const float dx = max_num(ahi.x, bhi.x) - min_num(alo.x, blo.x);
+    const float dy = max_num(ahi.y, bhi.y) - min_num(alo.y, blo.y);
+    const float dz = max_num(ahi.z, bhi.z) - min_num(alo.z, blo.z);
+    const float a = dx * dy + dy * dz + dz * dx;
+    return a == a ? a : __builtin_inff();
+}
+__global__ __launch_bounds__(256) void ploc_init(uint32_t n, const uint32_t* vals, const float4* box_lo, const float4* box_hi, int32_t* cluster, float4* lo, float4* hi) {
+    const uint32_t p = blockIdx.x * 256u + threadIdx.x;
+    if (p >= n) return;
+    const uint32_t t = vals[p];
+    cluster[p] = ~(int32_t)p;
+    lo[p] = box_lo[t];
+    hi[p] = box_hi[t];
+}
+__global__ __launch_bounds__(256) void ploc_nearest(uint32_t m, uint32_t radius, const float4* lo, const float4* hi, uint32_t* nearest) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= m) return;
+    const float4 alo = lo[i], ahi = hi[i];
+    float best_area = __builtin_inff();
+    uint32_t best_delta = 0xffffffffu, best_parity = 2u, best = i;
+    for (uint32_t delta = 1; delta <= radius; delta++) {
+        for (uint32_t side = 0; side < 2u; side++) {
+            if (side == 0u ? i < delta : i + delta >= m) continue;
+            const uint32_t j = side == 0u ? i - delta : i + delta;
+            const float area = union_area(alo, ahi, lo[j], hi[j]);
+            const uint32_t parity = ((side == 0u ? j : i) / delta) & 1u;
+            if (area < best_area || (area == best_area && (delta < best_delta || (delta == best_delta && parity < best_parity)))) {
+                best_area = area; best_delta = delta; best_parity = parity; best = j;
+            }
+        }
+    }
+    nearest[i] = best;
+}
+// per cluster: (stays in the array) << 32 | (is the lower end of a merging pair); the exclusive sums of both halves give the
+// cluster's next position and the running number of the node it creates
+__global__ __launch_bounds__(256) void ploc_flags(uint32_t m, const uint32_t* nearest, uint64_t* flags) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= m) return;
+    const uint32_t j = nearest[i];
+    const bool mutual = j != i && nearest[j] == i;
+    flags[i] = ((uint64_t)(mutual && i > j ? 0u : 1u) << 32) | (uint64_t)(mutual && i < j ? 1u : 0u);
+}
+// Nodes are numbered downwards from n - 2 in the order they are created, so the last one, the root, is node 0.
+// A node keeps the number of triangles below it in `last` until the triangle order is known.
+__global__ __launch_bounds__(256) void ploc_merge(uint32_t m, uint32_t n, uint32_t created, const uint32_t* nearest, const uint64_t* flags, const uint64_t* sums,
+                                                   const int32_t* cluster_in, const float4* lo_in, const float4* hi_in, int32_t* cluster_out, float4* lo_out,
+                                                   float4* hi_out, BuildNode* nodes, int32_t* node_parent, int32_t* leaf_parent, uint64_t* totals) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= m) return;
+    const uint64_t f = flags[i], before = sums[i];
+    if (i == m - 1u) *totals = before + f;
+    if ((f >> 32) == 0u) return;
+    const uint32_t pos = (uint32_t)(before >> 32);
+    if ((f & 1u) == 0u) {
+        cluster_out[pos] = cluster_in[i]; lo_out[pos] = lo_in[i]; hi_out[pos] = hi_in[i];
+        return;
+    }
+    const uint32_t j = nearest[i];
+    const int32_t id = (int32_t)((n - 2u) - (created + (uint32_t)before));
+    const int32_t a = cluster_in[i], b = cluster_in[j];
+    const float4 alo = lo_in[i], ahi = hi_in[i], blo = lo_in[j], bhi = hi_in[j];
+    const float4 ulo = make_float4(min_num(alo.x, blo.x), min_num(alo.y, blo.y), min_num(alo.z, blo.z), 0.f);
+    const float4 uhi = make_float4(max_num(ahi.x, bhi.x), max_num(ahi.y, bhi.y), max_num(ahi.z, bhi.z), 0.f);
+    BuildNode& nd = nodes[id];
+    nd.left = a; nd.right = b;
+    nd.first = 0u;
+    nd.last = (a < 0 ? 1u : nodes[a].last) + (b < 0 ? 1u : nodes[b].last);
+    nd.lo[0] = ulo.x; nd.lo[1] = ulo.y; nd.lo[2] = ulo.z; nd.hi[0] = uhi.x; nd.hi[1] = uhi.y; nd.hi[2] = uhi.z;
+    nd.cost = 0.f; nd.leaf = 0u;
+    if (a < 0) leaf_parent[(uint32_t)~a] = id; else node_parent[a] = id;
+    if (b < 0) leaf_parent[(uint32_t)~b] = id; else node_parent[b] = id;
+    cluster_out[pos] = id; lo_out[pos] = ulo; hi_out[pos] = uhi;
+}
+// The triangles of a subtree are not neighbours in Morton order any more; they are in the depth-first order of the tree.
+// Position of a leaf in that order: the triangles of every left sibling subtree on its way to the root.
+__global__ __launch_bounds__(256) void ploc_order(uint32_t n, const BuildNode* nodes, const int32_t* node_parent, const int32_t* leaf_parent, uint32_t* position) {
+    const uint32_t p = blockIdx.x * 256u + threadIdx.x;
+    if (p >= n) return;
+    int32_t ref = ~(int32_t)p, parent = leaf_parent[p];
+    uint32_t pos = 0u;
+    while (parent >= 0) {
+        const BuildNode& nd = nodes[parent];
+        if (nd.right == ref) pos += nd.left < 0 ? 1u : nodes[nd.left].last;
+        ref = parent;
+        parent = node_parent[parent];
+    }
+    position[p] = pos;
+}
+// every node's range [first, last] in the new order: set by its leftmost leaf, the only one that reaches it through left links alone
+__global__ __launch_bounds__(256) void ploc_ranges(uint32_t n, BuildNode* nodes, const int32_t* node_parent, const int32_t* leaf_parent, const uint32_t* position) {
+    const uint32_t p = blockIdx.x * 256u + threadIdx.x;
+    if (p >= n) return;
+    const uint32_t first = position[p];
+    int32_t ref = ~(int32_t)p, parent = leaf_parent[p];
+    while (parent >= 0 && nodes[parent].left == ref) {
+        const uint32_t count = nodes[parent].last;
+        nodes[parent].first = first;
+        nodes[parent].last = first + count - 1u;
+        ref = parent;
+        parent = node_parent[parent];
+    }
+}
+// leaf references, the triangle list and the leaves' parents go over to the new order
+__global__ __launch_bounds__(256) void ploc_reorder(uint32_t n, BuildNode* nodes, const uint32_t* position, const uint32_t* vals, const int32_t* leaf_parent,
+                                                     uint32_t* vals_out, int32_t* leaf_parent_out) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i < n) {
+        vals_out[position[i]] = vals[i];
+        leaf_parent_out[position[i]] = leaf_parent[i];
+    }
+    if (i + 1u < n) {
+        BuildNode& nd = nodes[i];
+        if (nd.left < 0) nd.left = ~(int32_t)position[(uint32_t)~nd.left];
+        if (nd.right < 0) nd.right = ~(int32_t)position[(uint32_t)~nd.right];
+    }
 }
 
 // ---- 4. boxes bottom-up + triangle records (written in sorted order) ---------------------------------------
@@ -402,14 +535,15 @@ size_t flat_build_blob_bytes(uint32_t triangle_count) {
     return 64 + (size_t)triangle_count * 64 + (size_t)triangle_count * 64;
 }
 
-hipError_t build_flat_bvh(hipStream_t s, const SceneView& sv, uint32_t n, uint32_t vertex_count, void* blob, size_t blob_bytes, float traversal_cost, int* status) {
+hipError_t build_flat_bvh(hipStream_t s, const SceneView& sv, uint32_t n, uint32_t vertex_count, void* blob, size_t blob_bytes, float traversal_cost, int cluster_radius, int* status) {
     *status = 0;
     if (n == 0 || vertex_count == 0 || blob_bytes < flat_build_blob_bytes(n)) { *status = -1; return hipSuccess; }
     const uint32_t node_capacity = n;
-    void* pool[16] = {};
+    void* pool[32] = {};
     int pooled = 0;
     auto cleanup = [&]() { for (int i = 0; i < pooled; i++) (void)hipFree(pool[i]); };
     auto take = [&](size_t bytes, void** out) -> hipError_t {
+        if (pooled >= (int)(sizeof pool / sizeof pool[0])) return hipErrorOutOfMemory;
         hipError_t e = hipMalloc(out, bytes ? bytes : 16);
         if (e == hipSuccess) pool[pooled++] = *out;
         return e;
@@ -448,7 +582,62 @@ hipError_t build_flat_bvh(hipStream_t s, const SceneView& sv, uint32_t n, uint32
     uint8_t* out = (uint8_t*)blob;
     float4* out_nodes = (float4*)(out + 64);
     float4* out_tris = (float4*)(out + 64 + (size_t)node_capacity * 64);
-    if (n > 1) hipLaunchKernelGGL(build_tree, dim3((n - 1 + 255u) / 256u), dim3(256), 0, s, n, keys_sorted, nodes, node_parent, leaf_parent);
+    if (n > 1 && cluster_radius <= 0) hipLaunchKernelGGL(build_tree, dim3((n - 1 + 255u) / 256u), dim3(256), 0, s, n, keys_sorted, nodes, node_parent, leaf_parent);
+    if (n > 1 && cluster_radius > 0) {
+        // the key arrays are free once the triangles are sorted: they hold the flags and their sums
+        uint64_t* flags = keys;
+        uint64_t* sums = keys_sorted;
+        int32_t* cluster[2] = { nullptr, nullptr };
+        float4 *clo[2] = { nullptr, nullptr }, *chi[2] = { nullptr, nullptr };
+        uint32_t *nearest = nullptr, *position = nullptr, *vals_ordered = nullptr;
+        int32_t* leaf_parent_ordered = nullptr;
+        uint64_t* totals = nullptr;
+        void* scan_temp = nullptr;
+        for (int k = 0; k < 2; k++) {
+            BUILD_CHECK(take((size_t)n * 4, (void**)&cluster[k]));
+            BUILD_CHECK(take((size_t)n * 16, (void**)&clo[k]));
+            BUILD_CHECK(take((size_t)n * 16, (void**)&chi[k]));
+        }
+        BUILD_CHECK(take((size_t)n * 4, (void**)&nearest));
+        BUILD_CHECK(take((size_t)n * 4, (void**)&position));
+        BUILD_CHECK(take((size_t)n * 4, (void**)&vals_ordered));
+        BUILD_CHECK(take((size_t)n * 4, (void**)&leaf_parent_ordered));
+        BUILD_CHECK(take(16, (void**)&totals));
+        size_t scan_bytes = 0;
+        BUILD_CHECK(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, flags, sums, (int)n, s));
+        BUILD_CHECK(take(scan_bytes, &scan_temp));
+        hipLaunchKernelGGL(ploc_init, dim3(blocks), dim3(256), 0, s, n, vals_sorted, box_lo, box_hi, cluster[0], clo[0], chi[0]);
+        uint32_t m = n, created = 0;
+        int cur = 0;
+        for (uint32_t round = 0; m > 1u; round++) {
+            if (round >= kClusterRoundsMax) { *status = -6; cleanup(); return hipSuccess; }
+            const uint32_t mb = (m + 255u) / 256u;
+            hipLaunchKernelGGL(ploc_nearest, dim3(mb), dim3(256), 0, s, m, (uint32_t)cluster_radius, clo[cur], chi[cur], nearest);
+            hipLaunchKernelGGL(ploc_flags, dim3(mb), dim3(256), 0, s, m, nearest, flags);
+            size_t bytes = scan_bytes;
+            BUILD_CHECK(hipcub::DeviceScan::ExclusiveSum(scan_temp, bytes, flags, sums, (int)m, s));
+            hipLaunchKernelGGL(ploc_merge, dim3(mb), dim3(256), 0, s, m, n, created, nearest, flags, sums, cluster[cur], clo[cur], chi[cur], cluster[cur ^ 1],
+                               clo[cur ^ 1], chi[cur ^ 1], nodes, node_parent, leaf_parent, totals);
+            BUILD_CHECK(hipGetLastError());
+            uint64_t host_totals = 0;
+            BUILD_CHECK(hipMemcpyAsync(&host_totals, totals, sizeof host_totals, hipMemcpyDeviceToHost, s));
+            BUILD_CHECK(hipStreamSynchronize(s));
+            const uint32_t kept = (uint32_t)(host_totals >> 32), merged = (uint32_t)host_totals;
+            if (merged == 0u || kept + merged != m) { *status = -6; cleanup(); return hipSuccess; }
+            created += merged;
+            m = kept;
+            cur ^= 1;
+        }
+        if (created != n - 1u) { *status = -6; cleanup(); return hipSuccess; }
+        const int32_t no_parent = -1;
+        BUILD_CHECK(hipMemcpyAsync(node_parent, &no_parent, sizeof no_parent, hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(ploc_order, dim3(blocks), dim3(256), 0, s, n, nodes, node_parent, leaf_parent, position);
+        hipLaunchKernelGGL(ploc_ranges, dim3(blocks), dim3(256), 0, s, n, nodes, node_parent, leaf_parent, position);
+        hipLaunchKernelGGL(ploc_reorder, dim3(blocks), dim3(256), 0, s, n, nodes, position, vals_sorted, leaf_parent, vals_ordered, leaf_parent_ordered);
+        BUILD_CHECK(hipGetLastError());
+        vals_sorted = vals_ordered;
+        leaf_parent = leaf_parent_ordered;
+    }
     hipLaunchKernelGGL(build_fit, dim3(blocks), dim3(256), 0, s, sv, n, vertex_count, vals_sorted, box_lo, box_hi, nodes, node_parent, leaf_parent, visits, out_tris, traversal_cost);
     BUILD_CHECK(hipGetLastError());
 

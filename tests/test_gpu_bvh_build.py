@@ -9,10 +9,12 @@ from path_tracer_amd import scenes
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module")
-def ctx():
+@pytest.fixture(scope="module", params=[0, 8], ids=["radix_tree", "clustered"])
+def ctx(request):
+    """Every test runs with both ways of building the binary tree: from the Morton keys' prefixes and by clustering."""
     from path_tracer_amd import hip
     c = hip.Context(0)
+    c.set_option("build.cluster_radius", request.param)
     yield c
     c.close()
 
