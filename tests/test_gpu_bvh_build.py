@@ -55,6 +55,28 @@ def test_coincident_triangles_and_flat_extents(ctx):
     check_flat_layout(build_from_triangles(ctx, far), far, np.arange(400))
 
 
+def test_chains_and_non_finite_vertices(ctx):
+    """A row of triangles that shrink quadratically (each cluster prefers its smaller neighbour: few mutual pairs per round) still
+    builds a valid tree; vertices that are NaN or infinite do not hang the builder (their boxes compare as infinitely large and pair
+    up by position)."""
+    k = 2000
+    size = (1.0 / (1 + np.arange(k)) ** 2)
+    x = np.cumsum(size)
+    chain = np.zeros((k, 9), np.float32)
+    chain[:, 0] = x; chain[:, 3] = x + size; chain[:, 6] = x; chain[:, 7] = size
+    h = check_flat_layout(build_from_triangles(ctx, chain), chain, np.arange(k))
+    assert 0 < h["max_depth"] <= 254
+    rng = np.random.default_rng(11)
+    broken = rng.random((5000, 9), dtype=np.float32)
+    broken[::7] = np.nan
+    broken[3::11, 0] = np.inf
+    header = build_from_triangles(ctx, broken)[:64].view(np.uint32)
+    assert header[0] == 0x46525450 and header[3] == 5000 and 0 < header[2] < 5000
+    nothing = np.full((3000, 9), np.nan, np.float32)
+    header = build_from_triangles(ctx, nothing)[:64].view(np.uint32)
+    assert header[3] == 3000 and 0 < header[2] < 3000
+
+
 @pytest.mark.parametrize("kind,target,wide", [("atrium", 6000, False), ("street_exterior", 150000, False), ("atrium", 5000, True)])
 def test_scene_build_and_frames_match_the_oracle(ctx, kind, target, wide):
     from path_tracer_amd import hip
