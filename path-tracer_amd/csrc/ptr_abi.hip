@@ -43,7 +43,7 @@ struct ImageRec {
     int format = 0;
     uint32_t sampler = 0;
     bool owned = false, alive = false;
-    void* tiled = nullptr;   // RGBA8 images the library owns: the texels again, in 4 x 4 tiles (what the shade step samples)
+    void* footprints = nullptr;   // RGBA8 images the library owns: the 2 x 2 texels of every bilinear lookup as one entry (what the shade step samples)
 };
 struct SamplerRec { int filter = 0, address = 0; bool alive = false; };
 
@@ -240,7 +240,7 @@ int upload_image_desc(ptr_ctx* c, ptr_handle h) {
     ptr::ImageDesc d;
     d.data = r.alive ? r.ptr : nullptr;
     d.width = r.w; d.height = r.h; d.format = (uint32_t)r.format; d.sampler = r.sampler;
-    d.tiled = r.alive ? (const uint32_t*)r.tiled : nullptr;
+    d.footprints = r.alive ? (const uint32_t*)r.footprints : nullptr;
     PTR_HIP_CHECK(c, hipMemcpyAsync(c->d_images + h, &d, sizeof d, hipMemcpyHostToDevice, c->stream));
     // the descriptor lives on the stack: finish the copy before returning
     PTR_HIP_CHECK(c, hipStreamSynchronize(c->stream));
@@ -943,7 +943,7 @@ int ptr_ctx_destroy(ptr_ctx* c) {
     }
     for (auto& b : c->buffers) if (b.alive && b.ptr) (void)hipFree(b.ptr);
     for (auto& im : c->images) if (im.alive && im.owned && im.ptr) (void)hipFree(im.ptr);
-    for (auto& im : c->images) if (im.alive && im.tiled) (void)hipFree(im.tiled);
+    for (auto& im : c->images) if (im.alive && im.footprints) (void)hipFree(im.footprints);
     if (c->shade_records) (void)hipFree(c->shade_records);
     if (c->unorm8_stage) (void)hipFree(c->unorm8_stage);
     if (c->d_validate) (void)hipFree(c->d_validate);
@@ -1104,15 +1104,15 @@ int ptr_image_create(ptr_ctx* c, uint32_t w, uint32_t h, int format, ptr_handle 
     void* mem = nullptr;
     PTR_HIP_CHECK(c, hipMalloc(&mem, (size_t)w * h * ts));
     PTR_HIP_CHECK(c, hipMemsetAsync(mem, 0, (size_t)w * h * ts, c->stream));
-    void* tiled = nullptr;
-    if (format == PTR_FORMAT_RGBA8_UNORM) {   // textures are sampled from a tiled copy, kept in step by ptr_image_upload
-        const size_t tiled_bytes = (size_t)((w + 3u) / 4u) * ((h + 3u) / 4u) * 64u;
-        if (hipMalloc(&tiled, tiled_bytes) != hipSuccess) { (void)hipFree(mem); return fail(c, PTR_E_HIP, "ptr_image_create: out of device memory for the tiled copy"); }
-        PTR_HIP_CHECK(c, hipMemsetAsync(tiled, 0, tiled_bytes, c->stream));
+    void* footprints = nullptr;
+    if (format == PTR_FORMAT_RGBA8_UNORM) {   // textures are sampled from a copy laid out per lookup (4 x the texels), kept in step by ptr_image_upload
+        const size_t footprint_bytes = (size_t)((w + 1u) / 2u) * ((h + 1u) / 2u) * 64u;
+        if (hipMalloc(&footprints, footprint_bytes) != hipSuccess) { (void)hipFree(mem); return fail(c, PTR_E_HIP, "ptr_image_create: out of device memory for the lookup copy"); }
+        PTR_HIP_CHECK(c, hipMemsetAsync(footprints, 0, footprint_bytes, c->stream));
     }
     const int rc_new = new_image(c, mem, true, w, h, format, sampler, out);
-    if (rc_new != PTR_OK) { if (tiled) (void)hipFree(tiled); return rc_new; }
-    if (tiled) { c->images[*out].tiled = tiled; return upload_image_desc(c, *out); }
+    if (rc_new != PTR_OK) { if (footprints) (void)hipFree(footprints); return rc_new; }
+    if (footprints) { c->images[*out].footprints = footprints; return upload_image_desc(c, *out); }
     return PTR_OK;
 }
 
@@ -1133,7 +1133,7 @@ int ptr_image_destroy(ptr_ctx* c, ptr_handle h) {
     if ((rc = drain_frames(c))) return rc;
     PTR_HIP_CHECK(c, hipStreamSynchronize(c->stream));
     if (im->owned) PTR_HIP_CHECK(c, hipFree(im->ptr));
-    if (im->tiled) PTR_HIP_CHECK(c, hipFree(im->tiled));
+    if (im->footprints) PTR_HIP_CHECK(c, hipFree(im->footprints));
     *im = ImageRec();
     return upload_image_desc(c, h);
 }
@@ -1146,7 +1146,7 @@ int ptr_image_upload(ptr_ctx* c, ptr_handle h, const void* texels) {
     int rc = enter(c); if (rc) return rc;
     if ((rc = drain_frames(c))) return rc;  // frames in flight may sample this image
     PTR_HIP_CHECK(c, hipMemcpyAsync(im->ptr, texels, (size_t)im->w * im->h * texel_size(im->format), hipMemcpyHostToDevice, c->stream));
-    if (im->tiled) PTR_HIP_CHECK(c, ptr::launch_tile_rgba8(c->stream, im->ptr, im->tiled, im->w, im->h));
+    if (im->footprints) PTR_HIP_CHECK(c, ptr::launch_footprints_rgba8(c->stream, im->ptr, im->footprints, im->w, im->h));
     PTR_HIP_CHECK(c, hipStreamSynchronize(c->stream));
     c->shared_epoch = ++c->write_epoch;
     return PTR_OK;

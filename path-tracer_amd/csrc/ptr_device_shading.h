@@ -34,13 +34,14 @@ struct ImageDesc {  // one entry of the bindless image table
     uint32_t width, height;
     uint32_t format;   // PTR_FORMAT_*
     uint32_t sampler;  // bindless sampler index
-    // RGBA8 images the library owns: the same texels in 4 x 4 tiles of 64 bytes, tile rows of ceil(width / 4) tiles -- the four
-    // texels of a bilinear fetch then lie in one 64-byte piece of memory nine times out of sixteen instead of never (two rows
-    // of a row-major image are a whole row apart).  nullptr: no tiled copy, fetch from `data`.
-    const uint32_t* tiled;
+    // RGBA8 images the library owns: for every texel position (i, j) the four texels a bilinear REPEAT lookup with its
+    // upper-left corner there reads -- (i, j), (i+1, j), (i, j+1), (i+1, j+1), the +1 wrapped -- as one 16-byte entry, the
+    // entries in 2 x 2 tiles of 64 bytes (tile rows of ceil(width / 2) tiles).  A lookup is then ONE 16-byte load from one
+    // 64-byte piece of memory instead of four 4-byte loads from up to four.  nullptr: no such copy, fetch from `data`.
+    const uint32_t* footprints;
 };
-PTR_DEV size_t tiled_texel(uint32_t tiles_x, int32_t i, int32_t j) {
-    return ((size_t)((uint32_t)j >> 2) * tiles_x + ((uint32_t)i >> 2)) * 16u + (((uint32_t)j & 3u) << 2) + ((uint32_t)i & 3u);
+PTR_DEV size_t footprint_entry(uint32_t tiles_x, uint32_t i, uint32_t j) {
+    return ((size_t)(j >> 1) * tiles_x + (i >> 1)) * 4u + ((j & 1u) << 1) + (i & 1u);
 }
 
 struct Capture { int32_t prim0; float t0; int32_t prim1; float t1; };
@@ -232,10 +233,9 @@ PTR_DEV f4 sample_bindless(const SceneView& sv, uint32_t texture_id, float u, fl
     j0 = j0 < 0 ? j0 + H : (j0 >= H ? j0 - H : j0);
     j1 = j1 < 0 ? j1 + H : (j1 >= H ? j1 - H : j1);
     uint32_t p00, p10, p01, p11;
-    if (d.tiled) {
-        const uint32_t tiles_x = (d.width + 3u) >> 2;
-        p00 = d.tiled[tiled_texel(tiles_x, i0, j0)]; p10 = d.tiled[tiled_texel(tiles_x, i1, j0)];
-        p01 = d.tiled[tiled_texel(tiles_x, i0, j1)]; p11 = d.tiled[tiled_texel(tiles_x, i1, j1)];
+    if (d.footprints) {
+        const uint4 e = ((const uint4*)d.footprints)[footprint_entry((d.width + 1u) >> 1, (uint32_t)i0, (uint32_t)j0)];
+        p00 = e.x; p10 = e.y; p01 = e.z; p11 = e.w;
     } else {
         const uint32_t* texels = (const uint32_t*)d.data;
         p00 = texels[(size_t)j0 * W + i0]; p10 = texels[(size_t)j0 * W + i1];

@@ -64,8 +64,9 @@ hipError_t launch_tonemap(hipStream_t s, const SceneMeta* meta, const ImageDesc*
 hipError_t launch_linearize_resolve(hipStream_t s, const ImageDesc* images, uint32_t output_index, uint32_t accumulation_index,
                                     uint32_t pixels, bool resolve);
 
-// Fills the 4 x 4-tiled copy of a row-major RGBA8 image (ceil(width / 4) * ceil(height / 4) * 64 bytes).
-hipError_t launch_tile_rgba8(hipStream_t s, const void* linear, void* tiled, uint32_t width, uint32_t height);
+// Fills the lookup copy of a row-major RGBA8 image: one 16-byte entry of 2 x 2 texels per texel position, the entries in
+// 2 x 2 tiles (ceil(width / 2) * ceil(height / 2) * 64 bytes).
+hipError_t launch_footprints_rgba8(hipStream_t s, const void* linear, void* footprints, uint32_t width, uint32_t height);
 // RGBA32F texels -> RGBA8 UNORM words (clamp, x 255, round to nearest): the conversion of the reference's present blit.
 hipError_t launch_unorm8_pack(hipStream_t s, const void* image, uint32_t texels, void* packed);
 

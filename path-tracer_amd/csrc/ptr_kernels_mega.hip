@@ -148,13 +148,19 @@ hipError_t launch_linearize_resolve(hipStream_t s, const ImageDesc* images, uint
     return hipGetLastError();
 }
 
-// The tiled copy of an RGBA8 image (ImageDesc::tiled): texel (i, j) of the row-major image goes to tiled_texel(i, j).
-__global__ __launch_bounds__(256) void ptr_tile_rgba8(const uint32_t* linear, uint32_t* tiled, uint32_t width, uint32_t height) {
+// The lookup copy of an RGBA8 image (ImageDesc::footprints): entry (i, j) holds the 2 x 2 texels of the bilinear REPEAT lookup whose
+// upper-left texel is (i, j).
+__global__ __launch_bounds__(256) void ptr_footprints_rgba8(const uint32_t* linear, uint32_t* footprints, uint32_t width, uint32_t height) {
     const uint32_t i = blockIdx.x * 16u + (threadIdx.x & 15u), j = blockIdx.y * 16u + (threadIdx.x >> 4);
-    if (i < width && j < height) tiled[tiled_texel((width + 3u) >> 2, (int32_t)i, (int32_t)j)] = linear[(size_t)j * width + i];
+    if (i >= width || j >= height) return;
+    const uint32_t i1 = i + 1u == width ? 0u : i + 1u, j1 = j + 1u == height ? 0u : j + 1u;
+    uint4 e;
+    e.x = linear[(size_t)j * width + i]; e.y = linear[(size_t)j * width + i1];
+    e.z = linear[(size_t)j1 * width + i]; e.w = linear[(size_t)j1 * width + i1];
+    ((uint4*)footprints)[footprint_entry((width + 1u) >> 1, i, j)] = e;
 }
-hipError_t launch_tile_rgba8(hipStream_t s, const void* linear, void* tiled, uint32_t width, uint32_t height) {
-    hipLaunchKernelGGL(ptr_tile_rgba8, dim3((width + 15u) / 16u, (height + 15u) / 16u), dim3(256), 0, s, (const uint32_t*)linear, (uint32_t*)tiled, width, height);
+hipError_t launch_footprints_rgba8(hipStream_t s, const void* linear, void* footprints, uint32_t width, uint32_t height) {
+    hipLaunchKernelGGL(ptr_footprints_rgba8, dim3((width + 15u) / 16u, (height + 15u) / 16u), dim3(256), 0, s, (const uint32_t*)linear, (uint32_t*)footprints, width, height);
     return hipGetLastError();
 }
 

@@ -718,7 +718,7 @@ def test_several_samples_per_dispatch_with_the_partitions_and_where_it_is_refuse
 
 
 def test_texture_extents_that_are_no_multiple_of_the_tile(ctx):
-    """The shade step samples RGBA8 textures from a copy in 4 x 4 tiles; extents of 1, 3, 5, 10 ... texels leave partly
+    """The shade step samples RGBA8 textures from a copy with one entry of 2 x 2 texels per lookup position, in 2 x 2 tiles; extents of 1, 3, 5, 10 ... texels leave partly
     filled tiles at the right and bottom edges, and REPEAT addressing wraps from them to the first column and row."""
     rng = np.random.default_rng(11)
     for (aw, ah), (mw, mh) in (((10, 6), (5, 3)), ((1, 1), (2, 7)), ((13, 4), (4, 13))):
@@ -728,7 +728,7 @@ def test_texture_extents_that_are_no_multiple_of_the_tile(ctx):
             img, gs, _, _ = gpu_frames(ctx, b, 2, pipeline)
             ref, _, _ = oracle_for(b, gs, 2, use_flat=use_flat)
             assert_same(img, ref, f"{pipeline}, textures {aw}x{ah} and {mw}x{mh}")
-        again = rng.integers(0, 256, (ah, aw, 4), dtype=np.uint8)    # a second upload replaces the tiled copy too
+        again = rng.integers(0, 256, (ah, aw, 4), dtype=np.uint8)    # a second upload replaces the lookup copy too
         gs.textures[1].update(again)
         gs.texture_table[gs.textures[1].bindless_index] = again
         img, _, _, _ = gpu_frames(ctx, b, 2, "compute.wavefront", gpu_scene=gs)
