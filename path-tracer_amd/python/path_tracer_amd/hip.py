@@ -464,8 +464,15 @@ class FrameLoop:
         self.sample_index += samples
         self.output, self.accumulation = self.accumulation, self.output
 
-    def frames(self, count):
-        """`count` samples, `samples_per_dispatch` at a time (the last dispatch takes what is left)."""
+    def frames(self, count, schedule=None):
+        """`count` samples, `samples_per_dispatch` at a time (the last dispatch takes what is left); or, with `schedule`,
+        as dispatches of exactly those sizes (they must add up to `count`).  The image is the same either way."""
+        if schedule is not None:
+            if sum(schedule) != count or min(schedule) < 1:
+                raise ValueError(f"dispatch sizes {schedule} do not add up to {count} samples")
+            for n in schedule:
+                self.frame(n)
+            return
         while count > 0:
             n = min(count, self.samples_per_dispatch)
             self.frame(n)

@@ -19,20 +19,21 @@ def main():
     ap.add_argument("--worlds", type=int, nargs="+", default=[1, 2, 4, 8])
     ap.add_argument("--per-dispatch", type=int, nargs="+", default=[10, 16, 20])
     ap.add_argument("--rounds", type=int, default=5)
+    ap.add_argument("--schedules", nargs="*", default=[], help='explicit dispatch sizes to try as well, e.g. "13,7" "12,8" (each must add up to --steps)')
     args = ap.parse_args()
     from path_tracer_amd import hip
     sc, nodes, flat, meta, _ = bench.build_scene(args, 0)
     ctx = hip.Context(0)
     gpu = hip.GpuScene(ctx, sc, nodes, flat, meta)
-    def measure(world, per):
+    def measure(world, per, schedule=None):
         ctx.set_partition(0, world, args.stripe_rows)
         loop = hip.FrameLoop(ctx, gpu, args.width, args.height, args.pipeline, samples_per_dispatch=min(64, per))
-        loop.frames(2 * min(64, per)); ctx.sync()
+        loop.frames(2 * min(64, per)); ctx.sync()   # both frame slots sized for the largest dispatch
         best = 1e9
         for _ in range(args.rounds):
             loop.reset()
             t0 = time.perf_counter()
-            loop.frames(args.steps)
+            loop.frames(args.steps, schedule)
             ctx.sync()
             best = min(best, time.perf_counter() - t0)
         return best
@@ -47,6 +48,11 @@ def main():
             t = measure(world, per)
             print(f"world {world}  samples per dispatch {min(64, per):2d}: {t * 1e3:7.3f} ms for {args.steps} steps"
                   f"   render-only efficiency {t1_best / (world * t):.3f} (against the best one-GPU time, {t1_best * 1e3:.3f} ms)", flush=True)
+    for text in args.schedules:
+        schedule = [int(v) for v in text.split(",")]
+        for world in args.worlds:
+            t = measure(world, max(schedule), schedule)
+            print(f"world {world}  dispatches of {text}: {t * 1e3:7.3f} ms for {args.steps} steps   render-only efficiency {t1_best / (world * t):.3f}", flush=True)
     ctx.set_partition(0, 1, 8)
     ctx.close()
 
