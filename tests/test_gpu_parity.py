@@ -644,6 +644,15 @@ def test_several_samples_per_dispatch_equal_as_many_single_sample_frames(ctx, ki
         loop.frames(7 - per_dispatch)
         assert loop.sample_index == 8
         assert_same(loop.latest().read(), ref, f"{per_dispatch} samples per dispatch")
+    # explicit dispatch sizes: 2 + 1 + 4, and sizes that do not add up are refused before anything is dispatched
+    gs.set_meta(b["meta"])
+    loop = hip.FrameLoop(ctx, gs, w, h, "compute")
+    loop.frames(7, schedule=[2, 1, 4])
+    assert loop.sample_index == 8
+    assert_same(loop.latest().read(), ref, "dispatches of 2, 1 and 4 samples")
+    with pytest.raises(ValueError):
+        loop.frames(7, schedule=[3, 3])
+    assert loop.sample_index == 8
     # work counters of one batch of three = the oracle's three frames added up
     gs.set_meta(b["meta"])
     loop = hip.FrameLoop(ctx, gs, w, h, "compute", samples_per_dispatch=3)
