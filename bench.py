@@ -312,19 +312,20 @@ def result_line(args, sc, W, H, world, tiles, elapsed, t1_elapsed, rays_total, s
         pixels = W * H * args.steps // (world if tiles else 1)
         paths = stats["rays"]                        # one path record per ray traced
         survivors = max(0, stats["rays"] - pixels)   # rays of bounce >= 1 are the survivors some shade launch wrote
-        shade_bytes = 64 * paths + 48 * survivors + (80 + 48 + 32) * stats["shaded"] + 16 * pixels
+        # (primary rays carry no throughput record: 48 B instead of 64 B read for one path per pixel and sample)
+        shade_bytes = 64 * paths - 16 * pixels + 48 * survivors + (80 + 48 + 32) * stats["shaded"] + 16 * pixels
         dispatches = -(-args.steps // max(1, pmc_traffic.samples_per_dispatch))
         acc_bytes = 16 * pixels + 32 * (pixels // args.steps) * dispatches   # every sample is read; the images once per dispatch
-        gen_bytes = 48 * pixels
+        gen_bytes = 32 * pixels
         others = []
         if solo.get("wavefront.shade", {}).get("launches"):
             others.append(kernel_roofline("wavefront.shade", shade_bytes, solo["wavefront.shade"], line_workload,
-                                          "per path 64 B (origin, direction, throughput, hit) + per survivor 48 B written + per shaded hit 80 B record + 48 B material + 2 x 4 texels + 16 B sample per finished path"))
+                                          "per path 64 B (origin, direction, throughput, hit; 48 B for a primary ray, whose throughput is 1 and not stored) + per survivor 48 B written + per shaded hit 80 B record + 48 B material + 2 x 4 texels + 16 B sample per finished path"))
         if solo.get("wavefront.accumulate", {}).get("launches"):
             others.append(kernel_roofline("wavefront.accumulate", acc_bytes, solo["wavefront.accumulate"], line_workload,
                                           "per sample 16 B sample read; per dispatch and pixel 16 B accumulation read + 16 B output write"))
         if solo.get("wavefront.generate", {}).get("launches"):
-            others.append(kernel_roofline("wavefront.generate", gen_bytes, solo["wavefront.generate"], line_workload, "per pixel 48 B of queue records written"))
+            others.append(kernel_roofline("wavefront.generate", gen_bytes, solo["wavefront.generate"], line_workload, "per pixel 32 B of queue records written (origin | pixel, direction | seed)"))
         line["roofline"]["other_kernels_solo"] = others
         total = algo_bytes + shade_bytes + acc_bytes + gen_bytes
         line["roofline"]["frame_level"] = {"algorithmic_bytes_per_step": total / args.steps, "achieved": total / elapsed / 1e9,

@@ -57,7 +57,7 @@ __global__ __launch_bounds__(256) void ptr_wf_generate(SceneView sv, WavefrontSc
     w.ray_o[0][slot] = make_float4(r.origin.x, r.origin.y, r.origin.z,
                                    __uint_as_float(valid ? sample_in_batch * (m.width * m.height) + gy * m.width + gx : kInvalidPixel));
     w.ray_d[0][slot] = make_float4(r.dir.x, r.dir.y, r.dir.z, __uint_as_float(seed));
-    w.path_t[0][slot] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
+    // (the throughput record of a primary ray is not written: it is 1, and the shade step of bounce 0 knows that)
 }
 
 // ---- extend --------------------------------------------------------------------------------------------
@@ -607,7 +607,9 @@ __global__ __launch_bounds__(kShadeThreads) void ptr_wf_shade(SceneView sv, Wave
     uint32_t seed = 0u;
     unsigned long long shaded = 0;
     if (live) {
-        const float4 rd = w.ray_d[gen][i], pt = w.path_t[gen][i];
+        const float4 rd = w.ray_d[gen][i];
+        float4 pt = make_float4(1.0f, 1.0f, 1.0f, 0.0f);   // primary rays carry no throughput record
+        if (bounce != 0u) pt = w.path_t[gen][i];
         r.origin = mk3(ro.x, ro.y, ro.z);
         r.dir = mk3(rd.x, rd.y, rd.z);
         throughput = mk3(pt.x, pt.y, pt.z);
