@@ -18,6 +18,17 @@ namespace ptr {
 constexpr float kBoxPad = 1.0000002384185791015625f;  // 1 + 2^-22: boxes cull conservatively
 
 constexpr uint32_t kInvalidPixel = 0xffffffffu;  // queue slot that holds no path (frame edge / foreign stripe)
+// streaming accesses to the queues: every record is written once and read once or twice, nothing of it should displace the tree
+typedef float v4f __attribute__((ext_vector_type(4)));
+PTR_DEV float4 stream_load(const float4* p) {
+    const v4f r = __builtin_nontemporal_load((const v4f*)p);
+    return make_float4(r.x, r.y, r.z, r.w);
+}
+PTR_DEV void stream_store(float4* p, float4 v) {
+    const v4f r = { v.x, v.y, v.z, v.w };
+    __builtin_nontemporal_store(r, (v4f*)p);
+}
+
 
 // ---- generate ------------------------------------------------------------------------------------------
 // One wave per 8x8 tile of the rows this GPU owns; slot = wave * 64 + lane, so the primary-ray queue needs
@@ -342,7 +353,7 @@ __global__ __launch_bounds__(kExtendThreads, TWO_LEVEL ? 6 : 4) void ptr_wf_exte
 
         // finished rays publish their hit and free the lane
         if (slot != kInvalidPixel && cur == kTraversalDone) {
-            w.hits[slot] = make_float4(best_t, best_u, best_v, __int_as_float(best_prim));
+            stream_store(&w.hits[slot], make_float4(best_t, best_u, best_v, __int_as_float(best_prim)));
             if (TWO_LEVEL) w.hit_instance[slot] = best_inst;
             slot = kInvalidPixel;
         }
@@ -597,7 +608,7 @@ __global__ __launch_bounds__(kShadeThreads) void ptr_wf_shade(SceneView sv, Wave
     const uint32_t i = blockIdx.x * kShadeThreads + threadIdx.x;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     float4 ro = make_float4(0, 0, 0, __uint_as_float(kInvalidPixel));
-    if (i < count) ro = w.ray_o[gen][i];
+    if (i < count) ro = stream_load(&w.ray_o[gen][i]);
     const uint32_t pixel = __float_as_uint(ro.w);
     const bool live = pixel != kInvalidPixel;
 
@@ -607,14 +618,14 @@ __global__ __launch_bounds__(kShadeThreads) void ptr_wf_shade(SceneView sv, Wave
     uint32_t seed = 0u;
     unsigned long long shaded = 0;
     if (live) {
-        const float4 rd = w.ray_d[gen][i];
+        const float4 rd = stream_load(&w.ray_d[gen][i]);
         float4 pt = make_float4(1.0f, 1.0f, 1.0f, 0.0f);   // primary rays carry no throughput record
-        if (bounce != 0u) pt = w.path_t[gen][i];
+        if (bounce != 0u) pt = stream_load(&w.path_t[gen][i]);
         r.origin = mk3(ro.x, ro.y, ro.z);
         r.dir = mk3(rd.x, rd.y, rd.z);
         throughput = mk3(pt.x, pt.y, pt.z);
         seed = __float_as_uint(rd.w);
-        const float4 h4 = w.hits[i];
+        const float4 h4 = stream_load(&w.hits[i]);
         Hit h; h.t = h4.x; h.u = h4.y; h.v = h4.z; h.prim = __float_as_int(h4.w);
         if (sv.instance_records && h.prim >= 0) h.inst = w.hit_instance[i];
         if (STATS && h.prim >= 0) shaded = 1;
@@ -626,7 +637,7 @@ __global__ __launch_bounds__(kShadeThreads) void ptr_wf_shade(SceneView sv, Wave
         }
         go_on = shade_bounce(sv, bounce, min_bounce, h, r, throughput, seed, result);
         if (go_on && bounce + 1u >= max_bounce) { go_on = false; result = mk3(0.0f, 0.0f, 0.0f); }  // loop exhausted: radiance
-        if (!go_on) w.samples[pixel] = make_float4(result.x, result.y, result.z, 1.0f);
+        if (!go_on) stream_store(&w.samples[pixel], make_float4(result.x, result.y, result.z, 1.0f));
     }
 
     const unsigned long long mask = __ballot(go_on);
@@ -641,9 +652,9 @@ __global__ __launch_bounds__(kShadeThreads) void ptr_wf_shade(SceneView sv, Wave
     if (go_on) {
         const uint32_t next = gen ^ 1u;
         const uint32_t slot = block_base + wave_offset[wave] + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-        w.ray_o[next][slot] = make_float4(r.origin.x, r.origin.y, r.origin.z, __uint_as_float(pixel));
-        w.ray_d[next][slot] = make_float4(r.dir.x, r.dir.y, r.dir.z, __uint_as_float(seed));
-        w.path_t[next][slot] = make_float4(throughput.x, throughput.y, throughput.z, 0.0f);
+        stream_store(&w.ray_o[next][slot], make_float4(r.origin.x, r.origin.y, r.origin.z, __uint_as_float(pixel)));
+        stream_store(&w.ray_d[next][slot], make_float4(r.dir.x, r.dir.y, r.dir.z, __uint_as_float(seed)));
+        stream_store(&w.path_t[next][slot], make_float4(throughput.x, throughput.y, throughput.z, 0.0f));
     }
     if (STATS && sv.stats) {
         for (int off = 32; off > 0; off >>= 1) shaded += __shfl_down(shaded, off);
