@@ -17,7 +17,7 @@ python3 scripts/pmc_summary.py "$OUT/pmc" > "$OUT/pmc_summary.txt"
 timeout -k 10 300 python3 bench.py --steps 20 --warmup 5 --cpu-seconds 0 > "$OUT/bench_plain.json" 2> "$OUT/bench_plain.err"
 python3 scripts/traffic_from_pmc.py "$OUT/pmc" "$OUT/bench_plain.json" "$OUT/traffic.json" > /dev/null
 echo "traffic.json done"
-[ -n "$SKIP_G3" ] && exit 0
+[ -n "$SKIP_G3" ] && exit 0   # SKIP_G3=1: the bench scene only (the 100 M-triangle passes take another ten minutes)
 # the one scene class HBM can bind: 100.7 M triangles written out (7.8 GB of nodes and triangle records)
 PMC_TARGET=bench scripts/pmc_passes.sh "$OUT/pmc_g3" --instances 6x6
 python3 scripts/pmc_summary.py "$OUT/pmc_g3" > "$OUT/pmc_summary_g3.txt"
