@@ -84,9 +84,8 @@ constexpr int32_t kEmptyChild = INT32_MIN;
 // relative to t.
 typedef float v2f __attribute__((ext_vector_type(2)));
 PTR_DEV v2f plane_pair(uint32_t lo_byte, uint32_t hi_byte, float a, float b) {
-    const v2f q = { (float)lo_byte, (float)hi_byte };
-    const v2f av = { a, a }, bv = { b, b };
-    return __builtin_elementwise_fma(q, av, bv);
+    const v2f r = { __builtin_fmaf((float)lo_byte, a, b), __builtin_fmaf((float)hi_byte, a, b) };
+    return r;
 }
 PTR_DEV float entry_key(float tnx, float tny, float tnz, float tfx, float tfy, float tfz, float min_t, float best_t) {
     const float t0 = max_num(max_num(max_num(tnx, tny), tnz), min_t);
