@@ -28,11 +28,20 @@ sys.path.insert(0, os.path.join(ROOT, "path-tracer_amd", "python"))
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak
-# VALU issue peak: 256 CUs x 4 SIMDs x 16 lanes per cycle at the 2.4 GHz peak engine clock, in lane-instructions per second
-VALU_PEAK_TLANE = 256 * 4 * 16 * 2.4e9 / 1e12
-# VALU instructions of one 4-wide node step (four quantised box tests, three compare-exchanges, push) and of one triangle test on their common
-# paths in the compiled traversal kernel (counted in the gfx950 ISA of csrc/ptr_kernels_wavefront.hip)
-VALU_PER_NODE, VALU_PER_TRIANGLE = 113, 67
+L2_PEAK_GBS = 34500.0           # aggregate L2 bandwidth of the 8 XCDs, measured
+INFINITY_CACHE_GATHER_GBS = 8600.0   # uniformly random rows of a 38 MB table (served by the 256 MB Infinity Cache), measured chip-wide
+CUS, SIMDS = 256, 1024
+# VALU issue peak.  A gfx950 SIMD has two 16-lane vector pipes: measured with scripts/microbench/valu_issue.hip, a wave64
+# instruction issues every 2.3 cycles when the stream is fp32 fma / mul / add, integer add, and / or / xor, right shifts or moves
+# on vector registers (either pipe takes them), and every 4.2 cycles when it is v_cndmask, v_cmp, v_min / v_max, a conversion, a
+# left shift, a packed fp32 form or anything with a scalar-register operand (one pipe only).  The peak is both pipes:
+# 256 CUs x 4 SIMDs x 32 lanes per cycle at the 2.4 GHz peak engine clock, in lane-instructions per second (= the fp32 vector
+# peak of 157 TFLOP/s counted as instructions).
+VALU_PEAK_TLANE = CUS * 4 * 32 * 2.4e9 / 1e12
+# VALU instructions of one 4-wide node step (four quantised box tests, three compare-exchanges, push) and of one triangle test on
+# their common paths in the compiled traversal kernel (counted in the gfx950 ISA of csrc/ptr_kernels_wavefront.hip; of the node
+# step's 125, 87 are of the one-pipe class)
+VALU_PER_NODE, VALU_PER_TRIANGLE = 125, 66
 
 
 def log(rank, *a):
@@ -182,7 +191,7 @@ def pmc_traffic(kernel, workload, samples_per_dispatch=None):
         samples_per_dispatch = pmc_traffic.samples_per_dispatch
     if rec is None or t.get("workload") != workload:
         return None, "profiles/traffic.json holds no counters for this kernel and workload", {}
-    extra = {k: rec[k] for k in ("valu_busy", "l2_hit_rate", "l1_hit_rate", "waves_waiting") if k in rec}
+    extra = {k: rec[k] for k in ("valu_busy", "l2_hit_rate", "l1_hit_rate", "waves_waiting", "per_launch") if k in rec}
     recorded = t.get("samples_per_dispatch", 1)
     if recorded == samples_per_dispatch:
         return rec["bytes_per_launch"], t.get("note", ""), extra
@@ -233,9 +242,12 @@ def kernel_roofline(name, algo_bytes_total, prof_rec, workload, note):
     achieved = algo_bytes_total / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
     traffic, _, counters = pmc_traffic(name, workload)
     avg_ms = ms / max(1, launches)
-    out = {"kernel": name, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+    counters = {k: v for k, v in counters.items() if k != "per_launch"}
+    out = {"kernel": name, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": min(1.0, achieved / HBM_PEAK_GBS),
            "traffic": traffic, "launches": launches, "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": algo_bytes_total / max(1, launches),
            "algorithmic_bytes": note, "counters": counters}
+    if achieved > HBM_PEAK_GBS:   # more than the memory can deliver: the bytes come out of the caches, the memory side moves `traffic`
+        out["served_by_caches"] = True
     if traffic and avg_ms > 0:
         out["traffic_over_algorithmic"] = traffic / (algo_bytes_total / max(1, launches))
         out["hbm_frac_measured"] = traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
@@ -254,11 +266,70 @@ def result_line(args, sc, W, H, world, tiles, elapsed, t1_elapsed, rays_total, s
     ks = solo.get(dominant, dict(launches=0, total_ms=0.0))
     solo_bytes = algo_bytes * ks["launches"] / max(1, k["launches"]) if k["launches"] else algo_bytes
     traffic, traffic_note, counters = pmc_traffic(dominant, line_workload)
+    if world > 1:   # the counter passes were taken on one GPU rendering whole frames: a rank's launches move other byte counts
+        traffic, traffic_note, counters = None, "profiles/traffic.json holds one-GPU counter passes; not applied to a rank of several", {}
     avg_ms = k["total_ms"] / max(1, k["launches"])
     solo_ms = ks["total_ms"] / max(1, ks["launches"])
     # lanes that held a ray, per inner-node step of a traversal wave (counting variant of the same kernel)
     lane_util = stats["nodes"] / (64.0 * stats["wave_inner_steps"]) if stats.get("wave_inner_steps") else None
     partition = "none" if world == 1 else ("tiles" if tiles else "samples")
+    launches = k["launches"] or ks["launches"] or 1
+    solo_s = solo_ms * 1e-3
+    algo_bytes_per_launch = algo_bytes / launches
+    traffic_part = {k2: v for k2, v in counters.items() if k2 != "per_launch"}
+    if wavefront:
+        # The roofline that binds the traversal kernel on a scene the caches hold: instruction issue.  Algorithmic
+        # lane-instructions (node steps and triangle tests only: no bookkeeping, every lane counted as useful) over the SOLO
+        # launch time, against what the SIMDs can issue.
+        lane_instr_per_launch = (VALU_PER_NODE * stats["nodes"] + VALU_PER_TRIANGLE * stats["triangles"]) / launches
+        valu_achieved = lane_instr_per_launch / solo_s / 1e12 if solo_s > 0 else 0.0
+        roofline = {"bound": "valu", "kernel": dominant, "achieved": valu_achieved, "peak": VALU_PEAK_TLANE, "unit": "Tlane-instr/s",
+                    "frac": valu_achieved / VALU_PEAK_TLANE, "traffic": traffic,
+                    "denominator": "solo launches (one dispatch in flight), HIP events on the stream the kernel runs on",
+                    "instructions_per_unit": {"node": VALU_PER_NODE, "triangle": VALU_PER_TRIANGLE},
+                    "peak_note": "two 16-lane vector pipes per SIMD at 2.4 GHz; only fma / mul / add / logic instructions on vector registers can use both (scripts/microbench/valu_issue.hip)"}
+        pl = counters.get("per_launch")
+        if pl and pl.get("GRBM_GUI_ACTIVE"):
+            cycles = pl["GRBM_GUI_ACTIVE"] / 8.0                    # the counter sums the 8 XCDs
+            issued = pl.get("SQ_INSTS_VALU", 0.0)
+            from_counters = {"cycles_per_launch": cycles,
+                             "issued_frac": issued * 64.0 / (SIMDS * 32.0 * cycles),
+                             "lanes_active": pl["SQ_THREAD_CYCLES_VALU"] / (64.0 * pl["SQ_ACTIVE_INST_VALU"]) if pl.get("SQ_ACTIVE_INST_VALU") and pl.get("SQ_THREAD_CYCLES_VALU") else None,
+                             "useful_over_issued": lane_instr_per_launch / (issued * 64.0) if issued else None,
+                             "frac": lane_instr_per_launch / (SIMDS * 32.0 * cycles),
+                             "one_pipe_share": pl.get("SQ_ACTIVE_INST_VALU", 0.0) * 4.0 / (SIMDS * cycles),
+                             "note": "replayed from profiles/traffic.json (separate rocprofv3 --pmc passes over this same command, taken when the file was made): "
+                                     "issued_frac = SQ_INSTS_VALU x 64 lanes over both pipes' lane-cycles; lanes_active = SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU); "
+                                     "frac = this run's algorithmic lane-instructions over the counter passes' cycles; one_pipe_share = the share of cycles ONE pipe "
+                                     "would be busy if it issued every vector instruction (what binds a stream of one-pipe-class instructions)"}
+            roofline["from_counters"] = from_counters
+            roofline["vector_memory"] = {"ta_busy": pl["TA_TA_BUSY_sum"] / (CUS * cycles) if pl.get("TA_TA_BUSY_sum") else None,
+                                         "ta_stalled_by_l1_share": pl["TA_ADDR_STALLED_BY_TC_CYCLES_sum"] / pl["TA_TA_BUSY_sum"] if pl.get("TA_TA_BUSY_sum") and pl.get("TA_ADDR_STALLED_BY_TC_CYCLES_sum") else None,
+                                         "l1_accesses_per_cycle_per_cu": pl["TCP_TOTAL_CACHE_ACCESSES_sum"] / (CUS * cycles) if pl.get("TCP_TOTAL_CACHE_ACCESSES_sum") else None,
+                                         "load_instructions_per_launch": pl.get("SQ_INSTS_VMEM_RD"),
+                                         "note": "the second resource in sight: a lane's 64-byte node is four 16-byte loads, each an L1 access of its own because the lanes of a wave sit at different nodes"}
+        roofline["cache_side"] = {"achieved": algo_bytes_per_launch / solo_s / 1e9 if solo_s > 0 else 0.0, "unit": "GB/s",
+                                  "algorithmic_bytes_per_launch": algo_bytes_per_launch,
+                                  "bytes_per_unit": {"node": node_bytes, "triangle": tri_bytes},
+                                  "note": "algorithmic bytes (64 B per node fetched + 64 B per triangle fetched) over the solo launch time: served by L1 / L2 / Infinity Cache, "
+                                          "so it is read against their rates, not against HBM"}
+        roofline["cache_side"]["vs_l2_peak"] = roofline["cache_side"]["achieved"] / L2_PEAK_GBS
+        roofline["cache_side"]["vs_infinity_cache_peak"] = roofline["cache_side"]["achieved"] / INFINITY_CACHE_GATHER_GBS
+        roofline["hbm"] = {"traffic": traffic, "achieved": traffic / solo_s / 1e9 if traffic and solo_s > 0 else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": traffic / solo_s / 1e9 / HBM_PEAK_GBS if traffic and solo_s > 0 else None,
+                           "traffic_over_algorithmic": traffic / algo_bytes_per_launch if traffic and algo_bytes_per_launch else None,
+                           "traffic_note": ("replayed from profiles/traffic.json (counter passes recorded when that file was made, not collected in this run); " + traffic_note) if traffic else traffic_note}
+    else:
+        roofline = {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": min(1.0, achieved / HBM_PEAK_GBS),
+                    "traffic": traffic, "traffic_note": traffic_note, "algorithmic_bytes_per_launch": algo_bytes_per_launch,
+                    "bytes_per_unit": {"node": node_bytes, "triangle": tri_bytes}}
+    roofline.update({"launches": k["launches"], "avg_launch_ms": avg_ms, "solo_avg_launch_ms": solo_ms,
+                     "nodes_per_ray": stats["nodes"] / max(1, stats["rays"]), "triangles_per_ray": stats["triangles"] / max(1, stats["rays"]),
+                     "counts_note": "nodes and triangles are counted by the counting variant of the same kernel, which walks every ray with one lane; "
+                                    "the timed variant finishes each wave's last ray with all 64 lanes and can touch a few more nodes on those rays",
+                     "limiter": "instruction issue on the one-pipe class under divergence together with the rate of L1 accesses (vector_memory): the BVH is served by L2 / Infinity Cache "
+                                "and the memory side moves a third of the algorithmic bytes, also on the 100 M-triangle scene",
+                     "lane_utilisation": lane_util, "counters": traffic_part})
     line = {
         "metric": "Mrays/s", "value": rays_total / elapsed / 1e6, "unit": "Mrays/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
@@ -270,41 +341,11 @@ def result_line(args, sc, W, H, world, tiles, elapsed, t1_elapsed, rays_total, s
                    "frames_in_flight": args.frames_in_flight, "bvh_builder": args.bvh,
                    "instancing": "none" if args.instances in ("", "1x1") else (f"{args.instances} copies through a top-level tree" if args.two_level else f"{args.instances} copies written out"),
                    "rays_per_step_per_gpu": stats["rays"] / args.steps},
+        # amortised: K steps rendered as batched dispatches with two dispatches in flight; one frame alone is single_frame_latency_ms
         "ms_per_frame": elapsed / args.steps * 1e3,
-        "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                     "launches": k["launches"], "avg_launch_ms": avg_ms,
-                     "algorithmic_bytes_per_launch": algo_bytes / max(1, k["launches"]),
-                     "bytes_per_unit": {"node": node_bytes, "triangle": tri_bytes},
-                     "nodes_per_ray": stats["nodes"] / max(1, stats["rays"]), "triangles_per_ray": stats["triangles"] / max(1, stats["rays"]),
-                     "counts_note": "nodes and triangles are counted by the counting variant of the same kernel, which walks every ray with one lane; "
-                                    "the timed variant finishes each wave's last ray with all 64 lanes and can touch a few more nodes on those rays",
-                     "traffic_note": traffic_note,
-                     # What binds: `frac` prices the ALGORITHMIC bytes against HBM as the measurement contract asks, but this scene's
-                     # BVH (40 MB of nodes + 179 MB of triangles) is served by L2 + the 256 MB Infinity Cache: the bytes that reach the
-                     # memory side are `traffic` (hbm_frac_measured).  The kernel is bound by VALU issue under divergence
-                     # (valu_roofline below, counters, lane_utilisation), not by HBM bandwidth.
-                     "limiter": "VALU issue under divergence (valu_roofline, counters.valu_busy, lane_utilisation); the BVH is served by L2 / Infinity Cache and the memory side moves a third of the algorithmic bytes, also on the 100 M-triangle scene",
-                     "hbm_frac_measured": (traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic and avg_ms > 0 else None,
-                     "traffic_over_algorithmic": (traffic / (algo_bytes / max(1, k["launches"]))) if traffic and k["launches"] else None,
-                     "lane_utilisation": lane_util,
-                     "counters": counters,
-                     # launches of overlapped frames share the CUs, so their event durations sum to more than the frame; the same
-                     # kernel with the GPU to itself (one frame in flight) is the clean per-launch denominator
-                     "solo": {"avg_launch_ms": solo_ms,
-                              "achieved": solo_bytes / (ks["total_ms"] * 1e-3) / 1e9 if ks["total_ms"] > 0 else 0.0,
-                              "frac": (solo_bytes / (ks["total_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS) if ks["total_ms"] > 0 else 0.0},
-                     # the whole step against the clock: every kernel's algorithmic bytes / ms_per_step
-                     "frame_level": None},
-        # The roofline that does bind the traversal kernel on a cache-resident scene: VALU issue.  Algorithmic lane-instructions
-        # (node steps and triangle tests only: no bookkeeping, every lane counted as useful) over the solo launch time, against
-        # what the SIMDs can issue.  The gap to 1 is lanes without work in a step (lane_utilisation, leaf / inner divergence),
-        # cycles without issue (counters.valu_busy) and the instructions around the two step bodies.
-        "valu_roofline": ({"kernel": dominant, "bound": "valu", "unit": "Tlane-instr/s", "peak": VALU_PEAK_TLANE,
-                           "achieved": (VALU_PER_NODE * stats["nodes"] + VALU_PER_TRIANGLE * stats["triangles"]) * (ks["launches"] / max(1, k["launches"]) if k["launches"] else 1.0)
-                                       / (ks["total_ms"] * 1e-3) / 1e12 if ks["total_ms"] > 0 else 0.0,
-                           "instructions_per_unit": {"node": VALU_PER_NODE, "triangle": VALU_PER_TRIANGLE},
-                           "denominator": "solo launches (one dispatch in flight)"} if wavefront else None),
+        "ms_per_frame_note": "throughput figure: the timed region's wall time / K, with several samples per dispatch and two dispatches in flight; "
+                             "the latency of one sample rendered alone is single_frame_latency_ms, the reference's one-dispatch-per-sample protocol is one_sample_per_dispatch",
+        "roofline": roofline,
         "kernels_ms_per_step_solo": {n: v["total_ms"] / solo_frames for n, v in sorted(solo.items()) if v["launches"]},
         "setup": build_times,
     }
@@ -328,10 +369,9 @@ def result_line(args, sc, W, H, world, tiles, elapsed, t1_elapsed, rays_total, s
             others.append(kernel_roofline("wavefront.generate", gen_bytes, solo["wavefront.generate"], line_workload, "per pixel 32 B of queue records written (origin | pixel, direction | seed)"))
         line["roofline"]["other_kernels_solo"] = others
         total = algo_bytes + shade_bytes + acc_bytes + gen_bytes
-        line["roofline"]["frame_level"] = {"algorithmic_bytes_per_step": total / args.steps, "achieved": total / elapsed / 1e9,
-                                           "frac": total / elapsed / 1e9 / HBM_PEAK_GBS}
-    if line.get("valu_roofline"):
-        line["valu_roofline"]["frac"] = line["valu_roofline"]["achieved"] / VALU_PEAK_TLANE
+        line["roofline"]["frame_level"] = {"algorithmic_bytes_per_step": total / args.steps, "achieved": total / elapsed / 1e9, "unit": "GB/s",
+                                           "vs_l2_peak": total / elapsed / 1e9 / L2_PEAK_GBS,
+                                           "note": "every kernel's algorithmic bytes over the step time; most of them are served by the caches (see roofline.hbm for what reaches the memory side)"}
     if world > 1 and tiles and t1_elapsed:
         line["strong_scaling"] = {"t1_ms_per_step": t1_elapsed / args.steps * 1e3, "tn_ms_per_step": elapsed / args.steps * 1e3,
                                   "efficiency": t1_elapsed / (world * elapsed),
@@ -365,8 +405,76 @@ def parity_check(sc, nodes, flat, meta, gpu_scene, image, samples, rows_per_band
                 against="CPU oracle (oracle/oracle.c) walking the same flattened layout, same seeds")
 
 
+def launch_ranks(n):
+    """`python3 bench.py --gpus N` without a launcher's environment: this process starts the N ranks itself -- one copy of this
+    command per GPU with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set, as torch.distributed.run would -- and
+    does so BEFORE anything here touches a GPU (a process that has initialised the GPU must not start or become another
+    program on this pool; counting devices does not initialise it).  Rank 0's standard output, the one JSON line, is this
+    process's; the other ranks' goes to standard error.  Returns the exit status: non-zero as soon as any rank fails."""
+    import socket
+    import subprocess
+    import torch
+    if not os.environ.get("PTR_BENCH_DRY_RUN") and "PTR_BENCH_DEVICE" not in os.environ:
+        found = torch.cuda.device_count()
+        if found < n:
+            print(f"[bench] --gpus {n}: this machine has {found} GPU(s).  (To rehearse the ranks on one GPU: PTR_BENCH_DEVICE=0 "
+                  f"PTR_BENCH_BACKEND=gloo.)", file=sys.stderr)
+            return 2
+    with socket.socket() as sock:                       # a free port for the rendezvous
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else sys.stderr))
+    status = 0
+    live = list(procs)
+    while live:
+        for p in list(live):
+            rc = p.poll()
+            if rc is None:
+                continue
+            live.remove(p)
+            if rc != 0 and status == 0:
+                status = rc if rc > 0 else 1
+                for q in live:                           # a rank that failed leaves the others waiting in a collective
+                    q.terminate()
+        time.sleep(0.05)
+    return status
+
+
+def dry_run(args, world, rank):
+    """PTR_BENCH_DRY_RUN=1: everything of a multi-rank run that needs no GPU -- the launcher, the rendezvous, the barriers and the
+    max-over-ranks reduction -- with nothing rendered.  The line says so (`dry_run`, value null); it exists for the CPU test of the
+    launcher and is never a measurement."""
+    import torch
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29517")
+    dist.init_process_group(os.environ.get("PTR_BENCH_BACKEND", "gloo"), rank=rank, world_size=world)
+    dist.barrier()
+    t0 = time.perf_counter()
+    dist.barrier()
+    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    seen = dist.get_world_size()
+    dist.barrier()
+    dist.destroy_process_group()
+    if rank == 0:
+        return {"metric": "Mrays/s", "value": None, "unit": "Mrays/s", "n_gpus": world, "ranks_seen": seen, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": None, "higher_is_better": True, "scaling": "strong" if args.partition == "tiles" else "weak", "vs_baseline": None,
+                "dtype": "f32", "data": "none", "dry_run": True, "barrier_ms": float(t[0].item()) * 1e3,
+                "config": {"workload": "nothing rendered: launcher and rendezvous only (PTR_BENCH_DRY_RUN)", "partition": args.partition}}
+    return None
+
+
 def main():
     args = make_parser().parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus))
 
     # Rank 0 must print ONE line on stdout.  Libraries underneath write there too (RCCL prints a version banner when the
     # first communicator is created): everything written to fd 1 from here on goes to stderr, the result line goes to the
@@ -375,14 +483,19 @@ def main():
     result_fd = os.dup(1)
     os.dup2(2, 1)
 
-    import torch
-    import torch.distributed as dist
-
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         log(rank, f"note: --gpus {args.gpus} but WORLD_SIZE {world}; using WORLD_SIZE")
+    if os.environ.get("PTR_BENCH_DRY_RUN"):
+        line = dry_run(args, world, rank)
+        if line is not None:
+            os.write(result_fd, (json.dumps(line) + "\n").encode())
+        return
+
+    import torch
+    import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the render path has no CPU fallback")
     # PTR_BENCH_DEVICE / PTR_BENCH_BACKEND exist to rehearse the multi-rank path on a one-GPU box
@@ -503,19 +616,31 @@ def main():
                 dist.barrier()
             torch.cuda.synchronize()
 
+        exchange_events = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        exchange_ms = [None]
+
         def timed(steps, with_exchange):
-            """`steps` frames from sample 1 on cleared images, barrier + device sync on both sides; returns (seconds, final image)."""
+            """`steps` frames from sample 1 on cleared images, barrier + device sync on both sides; returns (seconds, final image).
+            exchange_ms[0] = device time of the partition's exchange (pack + collective + unpack), HIP events on torch's stream, which
+            is the stream the exchange runs on (with --stream own it misses the library's pack / unpack kernels)."""
             loop.reset()
             img_a.zero_(); img_b.zero_()
             barrier()
             t0 = time.perf_counter()
             loop.frames(steps)
             ctx.flush()    # dispatches held back under "dispatch.coalesce" are enqueued now (nothing to do otherwise)
-            final = combine() if with_exchange else by_handle[loop.latest().handle]
+            if with_exchange:
+                exchange_events[0].record()
+                final = combine()
+                exchange_events[1].record()
+            else:
+                final = by_handle[loop.latest().handle]
             torch.cuda.synchronize()
             if multi:
                 dist.barrier()
-            return time.perf_counter() - t0, final
+            dt = time.perf_counter() - t0
+            exchange_ms[0] = exchange_events[0].elapsed_time(exchange_events[1]) if with_exchange else None
+            return dt, final
 
         # Untimed warm-up: the W steps asked for, and at least one dispatch of the timed size on each frame slot -- a slot's
         # scratch is sized by the largest dispatch it has seen, and growing it (hipFree + hipMalloc) belongs to set-up
@@ -529,6 +654,7 @@ def main():
         ctx.set_option("profile.extend_only", 1)
         ctx.profile_enable(not os.environ.get("PTR_BENCH_NO_LIVE_PROFILE"))
         elapsed, final = timed(args.steps, multi)
+        timed_exchange_ms = exchange_ms[0]
         ctx.profile_enable(False)
         prof = ctx.profile_read(reset=True)
         ctx.set_option("profile.extend_only", 0)
@@ -545,6 +671,20 @@ def main():
         torch.cuda.synchronize()
         ctx.profile_enable(False)
         solo = ctx.profile_read(reset=True)
+        # one sample rendered alone: one dispatch of one sample, nothing else in flight, host waits for it (the latency a caller
+        # sees who needs every frame before it issues the next; not a throughput figure)
+        keep_spd = loop.samples_per_dispatch
+        loop.samples_per_dispatch = 1
+        loop.reset()
+        loop.frames(2); torch.cuda.synchronize()
+        lat = []
+        for _ in range(min(args.steps, 10)):
+            t_l = time.perf_counter()
+            loop.frames(1)
+            torch.cuda.synchronize()
+            lat.append(time.perf_counter() - t_l)
+        single_frame_latency_ms = sorted(lat)[len(lat) // 2] * 1e3
+        loop.samples_per_dispatch = keep_spd
         ctx.set_option("frames.in_flight", args.frames_in_flight)
 
         # what a caller pays on top when it reads every finished frame back over PCIe (33 MB at 1080p)
@@ -593,12 +733,12 @@ def main():
         torch.cuda.synchronize()
 
         reduce_device = "cuda" if backend == "nccl" else "cpu"
-        t = torch.tensor([elapsed, t1_elapsed or 0.0], dtype=torch.float64, device=reduce_device)
+        t = torch.tensor([elapsed, t1_elapsed or 0.0, timed_exchange_ms or 0.0], dtype=torch.float64, device=reduce_device)
         work = torch.tensor([stats["rays"], stats["nodes"], stats["triangles"], stats["shaded"]], dtype=torch.float64, device=reduce_device)
         if multi:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dist.all_reduce(work, op=dist.ReduceOp.SUM)
-        elapsed, t1_elapsed = float(t[0].item()), float(t[1].item())
+        elapsed, t1_elapsed, timed_exchange_ms = float(t[0].item()), float(t[1].item()), float(t[2].item())
         rays_total = float(work[0].item())
 
         if rank == 0:
@@ -606,6 +746,10 @@ def main():
             line["config"]["samples_per_dispatch"] = loop.samples_per_dispatch
             line["config"]["dispatches_per_gpu"] = -(-args.steps // loop.samples_per_dispatch)
             line["config"]["warmup_steps_run"] = warmup_steps
+            line["ranks_seen"] = dist.get_world_size() if multi else 1
+            line["exchange_ms"] = timed_exchange_ms if multi else None
+            line["single_frame_latency_ms"] = single_frame_latency_ms
+            line["data"] = sc.get("data", "synthetic")
             if single_ms is not None:
                 line["one_sample_per_dispatch"] = {"ms_per_step": single_ms, "value": rays_total / (single_ms * 1e-3 * args.steps) / 1e6, "unit": "Mrays/s",
                                                     "note": "the same K steps as K dispatches of one sample each (the reference's frame protocol), same partition and exchange, outside the timed region",

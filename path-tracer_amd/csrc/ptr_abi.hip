@@ -1015,6 +1015,12 @@ int ptr_buffer_destroy(ptr_ctx* c, ptr_handle h) {
     int rc = enter(c); if (rc) return rc;
     if ((rc = drain_frames(c))) return rc;
     PTR_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+    if (b->flat_is_auto && b->flat) {
+        // the layout "bvh.auto_flatten" built for this node buffer lives behind a handle the caller never saw: it goes with the buffer
+        BufferRec& built = c->buffers[b->flat];
+        PTR_HIP_CHECK(c, hipFree(built.ptr));
+        built = BufferRec();
+    }
     PTR_HIP_CHECK(c, hipFree(b->ptr));
     *b = BufferRec();
     for (auto& o : c->buffers) { if (o.flat == h) o.flat = 0; if (o.instances == h) o.instances = 0; }
@@ -1296,8 +1302,11 @@ int ptr_bvh_build_flat(ptr_ctx* c, ptr_handle indices, ptr_handle positions, uin
     if (c->profile_on) { t0 = take_event(c); t1 = take_event(c); if (t0) (void)hipEventRecord(t0, c->stream); }
     const uint32_t vertex_count = (uint32_t)(vertices > 0xffffffffull ? 0xffffffffull : vertices);
     hipError_t e = ptr::build_flat_bvh(c->stream, sv, triangle_count, vertex_count, b.ptr, bytes, (float)c->opt_build_traversal_cost * 0.01f, c->opt_build_cluster_radius, &status);
-    // clustering that does not finish within its round limit (boxes that each prefer the next one along a long chain): the radix tree always finishes
-    if (e == hipSuccess && status == -6)
+    // A clustered tree can fail where the radix tree does not: clustering that does not finish within its round limit (-6: boxes
+    // that each prefer the next one along a long chain), or a tree as deep as its round count -- boxes that grow geometrically
+    // along the Morton curve merge one pair per round -- that exceeds the traversal stack or the level limit (-5, -2).  The
+    // radix tree's depth is bounded by the key bits plus log n: every failed clustered build is tried again with it.
+    if (e == hipSuccess && status != 0 && c->opt_build_cluster_radius != 0)
         e = ptr::build_flat_bvh(c->stream, sv, triangle_count, vertex_count, b.ptr, bytes, (float)c->opt_build_traversal_cost * 0.01f, 0, &status);
     if (c->profile_on && t0 && t1) { (void)hipEventRecord(t1, c->stream); c->profile["bvh.build_flat"].pending.emplace_back(t0, t1); }
     if (e != hipSuccess || status != 0) {

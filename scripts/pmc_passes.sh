@@ -6,8 +6,10 @@ set -e
 OUT=$1; shift
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 mkdir -p "$OUT"
+# PMC_PASSES="sq1 tcp": only those passes (default: all)
 run_pass() {
   name=$1; shift
+  if [ -n "$PMC_PASSES" ] && ! echo " $PMC_PASSES " | grep -q " $name "; then return 0; fi
   timeout -s KILL 240 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d "$OUT/$name" -o p -- python3 $TARGET $EXTRA > "$OUT/$name.log" 2>&1
   echo "pass $name done"
 }

@@ -15,6 +15,12 @@ NAMES = {"ptr_wf_extend<false": "wavefront.extend", "ptr_wf_shade<false": "wavef
          "ptr_wf_accumulate": "wavefront.accumulate", "ptr_compute_megakernel<false": "compute.megakernel"}
 
 
+RAW = {"sq1": ("SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_INSTS_VMEM_RD", "SQ_WAIT_INST_ANY", "SQ_WAIT_ANY"),
+       "sq2": ("SQ_THREAD_CYCLES_VALU", "SQ_INSTS_LDS", "SQ_INSTS_SALU", "SQ_ACTIVE_INST_ANY", "SQ_INSTS_BRANCH"),
+       "tcp": ("TCP_TOTAL_CACHE_ACCESSES_sum", "TCP_TCC_READ_REQ_sum", "TA_TA_BUSY_sum", "TA_ADDR_STALLED_BY_TC_CYCLES_sum", "GRBM_GUI_ACTIVE"),
+       "tcc": ("TCC_HIT_sum", "TCC_MISS_sum")}
+
+
 def mean_per_kernel(directory, counter):
     acc = {}
     for f in glob.glob(os.path.join(directory, "**", "*counter_collection.csv"), recursive=True):
@@ -54,6 +60,14 @@ def main():
             kernels[name]["l1_hit_rate"] = 1.0 - l1_miss.get(name, 0.0) / l1_req[name]
         if name in wait and wave_cycles.get(name):
             kernels[name]["waves_waiting"] = wait[name] / wave_cycles[name]
+        # the raw per-launch means bench.py derives its instruction-issue and vector-memory figures from
+        raw = {}
+        for pass_name, names in RAW.items():
+            for cname in names:
+                v = counter(pass_name, cname).get(name)
+                if v is not None:
+                    raw[cname] = v
+        kernels[name]["per_launch"] = raw
     doc = dict(workload=bench["config"]["workload"], samples_per_dispatch=bench["config"].get("samples_per_dispatch", 1), kernels=kernels,
                note="per launch, mean over the launches of a short bench.py run under rocprofv3 --pmc (FETCH_SIZE and WRITE_SIZE in separate "
                     "passes); bytes = 2 x FETCH_SIZE (gfx950 tallies 128-byte requests as 64) + WRITE_SIZE; the doubling is an upper bound for "
