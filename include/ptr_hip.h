@@ -126,7 +126,9 @@ int ptr_dispatch(ptr_ctx* ctx, const char* kernel, const uint8_t constants[64], 
  * records, counters and traversal-stack spill area of the wavefront pipeline in scratch it allocates (and re-allocates when a
  * larger frame or a deeper tree comes along); this entry point keeps them in ONE fixed 34 MB array per GPU that is part of the
  * library's device image and stays until the process ends, and calls no hipMalloc / hipFree / stream or event creation on the
- * way.  Same arguments, same images bit for bit.  Limits (PTR_E_RANGE beyond them): a frame of at most 163 840 queue slots
+ * way, nor does it wait for the stream: what would need a copy back to the host -- scene metadata in a buffer above 4 KB (no
+ * host copy is kept of those), a layout header no earlier ptr_dispatch has read -- fails with PTR_E_STATE instead.  Same
+ * arguments, same images bit for bit.  Limits (PTR_E_RANGE beyond them): a frame of at most 163 840 queue slots
  * -- ceil(width/8) * (ceil(height/8) + stripe_rows/8) * 64, e.g. 512 x 288 -- and a flattened layout whose header asks for a
  * traversal stack of at most 61 entries.  What ptr_dispatch does once per upload with allocations is not repeated here: the
  * scene buffers must have passed the contents check in an earlier ptr_dispatch (PTR_E_STATE otherwise, unless

@@ -113,6 +113,8 @@ struct ptr_ctx {
     // sample_index + 1, the two images swapped) are held back and rendered as ONE dispatch of that many samples
     int opt_coalesce = 1;           // dispatches held back at most (1 = every dispatch runs at once)
     int opt_auto_flatten = 0;       // 1: a "compute" dispatch with no flattened layout bound builds one on the GPU and binds it
+    int opt_coalesce_scratch_mb = 8192;   // frame scratch a chain of held-back dispatches may ask for (about 132 bytes per pixel and sample)
+    int opt_refuse_batches = 0;     // tests only: batched dispatches fail, so that the one-by-one replay of a held-back chain runs
     struct Pending {
         bool active = false;
         uint8_t last[64] = {};      // constant block of the newest dispatch held back
@@ -370,12 +372,15 @@ ParsedConstants parse_constants(const uint8_t* k) {
 }
 
 // Host view of the 160-byte metadata the constant block points at.
-int read_meta(ptr_ctx* c, uint64_t addr, ptr::SceneMeta* out) {
+// may_wait = false (ptr_dispatch_static): a metadata buffer without a host copy is refused instead of being copied back, which
+// would make the caller wait for the stream
+int read_meta(ptr_ctx* c, uint64_t addr, ptr::SceneMeta* out, bool may_wait = true) {
     ptr_handle h = 0;
     BufferRec* b = buffer_at(c, addr, sizeof(ptr::SceneMeta), &h);
     if (!b) return fail(c, PTR_E_STATE, "constant block: scene metadata address is not inside a registered buffer");
     const size_t off = (size_t)(addr - (uint64_t)(uintptr_t)b->ptr);
     if (!b->shadow.empty()) { memcpy(out, b->shadow.data() + off, sizeof *out); return PTR_OK; }
+    if (!may_wait) return fail(c, PTR_E_STATE, "ptr_dispatch_static: the scene metadata lies in a buffer larger than %zu bytes, of which the library keeps no host copy (reading it back would wait for the stream)", kShadowLimit);
     PTR_HIP_CHECK(c, hipMemcpyAsync(out, (const uint8_t*)b->ptr + off, sizeof *out, hipMemcpyDeviceToHost, c->stream));
     PTR_HIP_CHECK(c, hipStreamSynchronize(c->stream));
     return PTR_OK;
@@ -560,7 +565,7 @@ int dispatch_compute(ptr_ctx* c, const uint8_t constants[64], uint32_t gx, uint3
     ptr::SceneMeta meta;
     int rc = PTR_OK;
     if (batch) meta = batch->meta;
-    else if ((rc = read_meta(c, k.addr[0], &meta))) return rc;
+    else if ((rc = read_meta(c, k.addr[0], &meta, !no_alloc))) return rc;
     if (meta.width == 0 || meta.height == 0) return fail(c, PTR_E_STATE, "scene metadata: zero width/height");
     if (meta.downscale_factor < 1) return fail(c, PTR_E_STATE, "scene metadata: downscale_factor < 1");
     if (meta.sample_index == 0) return fail(c, PTR_E_STATE, "scene metadata: sample_index must start at 1 (1/sample_index weights the frame)");
@@ -601,6 +606,7 @@ int dispatch_compute(ptr_ctx* c, const uint8_t constants[64], uint32_t gx, uint3
     }
     sv.stats = c->stats_on ? c->d_stats : nullptr;
     sv.batch_samples = (uint32_t)c->opt_dispatch_samples;
+    if (batch && batch->count > 1u && c->opt_refuse_batches) return fail(c, PTR_E_STATE, "batched dispatch refused (debug.refuse_batches)");
     if (batch) {
         // dispatch i read the image dispatch i - 1 wrote: the chain starts from the first one's accumulation image -- the newest
         // one's accumulation image for an odd count, its output image for an even one -- and ends in the newest one's output
@@ -654,6 +660,8 @@ int dispatch_compute(ptr_ctx* c, const uint8_t constants[64], uint32_t gx, uint3
     }
 
     if (!flat_buf) return fail(c, PTR_E_STATE, "compute.wavefront: no flattened layout bound to the bvh buffer (ptr_bvh_bind_flat)");
+    if (no_alloc && (!flat_buf->flat_view_valid || (flat_buf->instances && !(find_buffer(c, flat_buf->instances) && find_buffer(c, flat_buf->instances)->top_view_valid))))
+        return fail(c, PTR_E_STATE, "ptr_dispatch_static: the header of the flattened layout has not been read yet (an earlier ptr_dispatch does that once per upload; here it would wait for the stream)");
     if (!flat_buf->flat_view_valid) {  // parse + validate the header once per upload
         struct Header { uint32_t magic, version, node_count, triangle_count; uint64_t nodes_offset, triangles_offset; int32_t root; uint32_t max_depth; float bounds[6]; } hd;
         if (flat_buf->size < sizeof hd) return fail(c, PTR_E_STATE, "flattened layout: blob shorter than its header");
@@ -821,11 +829,37 @@ int dispatch_compute(ptr_ctx* c, const uint8_t constants[64], uint32_t gx, uint3
     return PTR_OK;
 }
 
+// Frame scratch a chain of held-back dispatches may ask for ("dispatch.coalesce_scratch_mb", 8 GiB unless set): the queues, hits
+// and samples of one slot grow with the samples of the dispatch that renders the chain, about 132 bytes per pixel and sample
+// (17 GB for 64 samples at 1080p would be a surprise).  A chain that would pass it is rendered and a new one started.
+constexpr uint64_t kScratchBytesPerPath = 132;
+
+bool chain_fits(const ptr_ctx* c, const ptr::SceneMeta& meta, uint32_t count) {
+    const uint64_t paths = (uint64_t)meta.width * meta.height * count;
+    return paths < (1ull << 31) && paths * kScratchBytesPerPath <= ((uint64_t)c->opt_coalesce_scratch_mb << 20);
+}
+
 int flush_pending(ptr_ctx* c) {
     if (!c->pending.active) return PTR_OK;
     const ptr_ctx::Pending p = c->pending;
     c->pending.active = false;
-    return dispatch_compute(c, p.last, p.gx, p.gy, p.force, false, &p);
+    int rc = dispatch_compute(c, p.last, p.gx, p.gy, p.force, false, &p);
+    if (rc == PTR_OK || p.count < 2u) return rc;
+    // The batched dispatch was refused (its scratch could not be allocated, a precondition of batches that the single
+    // dispatches do not have): the frames the caller issued are still owed.  They run one by one, each with the constants
+    // and the metadata it was issued with -- dispatch i of the chain has the newest one's images, swapped when it lies an
+    // odd number of dispatches before it.
+    for (uint32_t i = 0; i < p.count; i++) {
+        ptr_ctx::Pending one = p;
+        one.count = 1;
+        one.meta.sample_index = p.meta.sample_index + i;
+        if ((p.count - 1u - i) & 1u) {
+            memcpy(one.last + 56, p.last + 60, 4);
+            memcpy(one.last + 60, p.last + 56, 4);
+        }
+        if ((rc = dispatch_compute(c, one.last, one.gx, one.gy, one.force, false, &one))) return rc;
+    }
+    return PTR_OK;
 }
 
 // A "compute" dispatch under "dispatch.coalesce" > 1: held back when it starts or continues an accumulation chain the batched
@@ -842,6 +876,9 @@ int dispatch_or_hold(ptr_ctx* c, const uint8_t constants[64], uint32_t gx, uint3
     if (can && !c->buffers[handles[1]].flat) can = false;   // no flattened layout bound: the megakernel's frame, or an error to report now
     // a dispatch that names no usable image fails now, not when it would have run
     if (can && (check_storage_image(c, k.output_index, "output") || check_storage_image(c, k.accumulation_index, "accumulation"))) can = false;
+    // what the batched dispatch asks beyond a single one: both images of one extent, and room for at least two samples
+    if (can && (c->images[k.output_index].w != c->images[k.accumulation_index].w || c->images[k.output_index].h != c->images[k.accumulation_index].h)) can = false;
+    if (can && !chain_fits(c, meta, 2u)) can = false;
     if (!can) {
         if ((rc = flush_pending(c))) return rc;
         return dispatch_compute(c, constants, gx, gy, force);
@@ -851,7 +888,7 @@ int dispatch_or_hold(ptr_ctx* c, const uint8_t constants[64], uint32_t gx, uint3
         const ParsedConstants last = parse_constants(p.last);
         ptr::SceneMeta expect = p.meta;
         expect.sample_index = p.meta.sample_index + p.count;
-        const bool next = p.gx == gx && p.gy == gy && p.force == force && p.meta.sample_index <= 0xffffffffu - p.count &&
+        const bool next = p.gx == gx && p.gy == gy && p.force == force && p.meta.sample_index <= 0xffffffffu - p.count && chain_fits(c, p.meta, p.count + 1u) &&
                           !memcmp(&meta, &expect, sizeof meta) && !memcmp(constants, p.last, 56) &&
                           k.output_index == last.accumulation_index && k.accumulation_index == last.output_index;
         if (next) {
@@ -1515,6 +1552,15 @@ int ptr_set_option(ptr_ctx* c, const char* key, int value) {
     if (!strcmp(key, "shade.pregather")) {
         if (value != 0 && value != 1) return fail(c, PTR_E_INVALID, "shade.pregather: 0 or 1");
         c->opt_shade_pregather = value;
+        return PTR_OK;
+    }
+    if (!strcmp(key, "dispatch.coalesce_scratch_mb")) {
+        if (value < 1) return fail(c, PTR_E_INVALID, "dispatch.coalesce_scratch_mb: at least 1");
+        c->opt_coalesce_scratch_mb = value;
+        return PTR_OK;
+    }
+    if (!strcmp(key, "debug.refuse_batches")) {
+        c->opt_refuse_batches = value != 0;
         return PTR_OK;
     }
     if (!strcmp(key, "extend.blocks_per_cu")) {

@@ -28,7 +28,8 @@ void ComputeRenderpass::set_constant(off_t offset, Buffer* buffer) {
     std::memcpy(constants + offset, &address, sizeof address);
 }
 
-void ComputeRenderpass::execute(hiprenderer&) {
+void ComputeRenderpass::execute(hiprenderer&, void* stream) {
+    if (stream != nullptr) hiprenderer::check(ptr_ctx_set_stream(hiprenderer::api, stream), "ptr_ctx_set_stream");
     hiprenderer::check(ptr_dispatch(hiprenderer::api, pipeline.c_str(), constants, (uint32_t)group_count_x, (uint32_t)group_count_y, (uint32_t)group_count_z),
                        "ptr_dispatch");
 }

@@ -22,7 +22,9 @@ public:
     void set_constant(off_t offset, Texture* texture);
     void set_constant(off_t offset, Buffer* buffer);
 
-    void execute(hiprenderer& renderer) final;
+    // include/compute-renderpass.hpp:26 execute(vkrenderer&, VkCommandBuffer): the command buffer becomes a hipStream_t.  A non-null
+    // stream becomes the context's stream (ptr_ctx_set_stream) and stays it until another one is named.
+    void execute(hiprenderer& renderer, void* stream = nullptr) final;
 
     Texture* output_texture = nullptr;
 

@@ -93,8 +93,18 @@ scene_source load_source(const std::string& path, bool apply_transforms, bool in
     if (ext == ".gltf" || ext == ".glb") return gltf(path).flatten(apply_transforms);
     return scene_source::load(path);
 }
-// --gpus N without --rank: one child process per GPU (started before this process touches a GPU), the worst exit code wins.
+// --gpus N without --rank: one child process per GPU, the worst exit code wins.  The children are this program again (fork +
+// exec of /proc/self/exe), which is only allowed from a process that has not initialised the GPU: main() calls this before its
+// first HIP call, and it refuses to start under a profiler, whose preloaded library initialises the GPU before main() runs.
 int launch_ranks(int argc, char** argv, uint32_t gpus, std::string rendezvous) {
+    for (const char* name : { "ROCP_TOOL_LIBRARIES", "ROCPROFILER_REGISTER_FORCE_LOAD", "HSA_TOOLS_LIB" }) {
+        const char* v = std::getenv(name);
+        if (v && *v) {
+            std::fprintf(stderr, "ptr_headless --gpus %u: not under a profiler (%s is set): its library initialises the GPU before this process "
+                                 "starts the ranks.  Profile one rank instead: --rank R --gpus %u --rendezvous DIR.\n", gpus, name, gpus);
+            return 2;
+        }
+    }
     const bool own_directory = rendezvous.empty();
     if (rendezvous.empty()) {
         char tmpl[] = "/tmp/ptr_headless_XXXXXX";
@@ -147,7 +157,8 @@ const char kUsage[] =
     "            --resume FILE (continue such a render up to --spp samples: same image as an uninterrupted run)\n"
     "  output    --out file.ppm | file.png (8 bits per channel, 256 * clamp(c, 0, 0.999)) | any other name (\"PTRF w h\\n\" + the float RGBA image)\n"
     "  GPUs      --gpus N (one process per GPU is started)   --partition tiles|samples   --stripe-rows N (a multiple of 8)\n"
-    "            --transport rccl|file   --rendezvous DIR   [--rank R --device D: set for the started processes]\n";
+    "            --transport rccl|file   --rendezvous DIR   [--rank R --device D: set for the started processes]\n"
+    "            (do not profile the --gpus N launcher: profile one rank, --rank R --gpus N --rendezvous DIR)\n";
 
 int main(int argc, char** argv) {
     std::string scene_path, out_path, pipeline = "compute", checkpoint_path, resume_path;
@@ -202,6 +213,7 @@ int main(int argc, char** argv) {
     if (scene_path.empty()) { std::fputs(kUsage, stderr); return 2; }
 
     if (gpus == 0 || (partition != "tiles" && partition != "samples")) { std::fprintf(stderr, "--gpus N >= 1, --partition tiles|samples\n"); return 2; }
+    // (Nothing above this line may call HIP -- no hiprenderer, no device query: launch_ranks() starts this program again.)
     if (gpus > 1 && rank < 0) return launch_ranks(argc, argv, gpus, rendezvous);
     if (gpus > 1 && (uint32_t)rank >= gpus) { std::fprintf(stderr, "--rank %d of %u\n", rank, gpus); return 2; }
     if (gpus == 1) rank = 0;

@@ -855,6 +855,56 @@ def test_coalescing_stops_where_the_chain_breaks(ctx):
         assert np.array_equal(want, got)
 
 
+def test_a_held_back_chain_stays_within_what_a_batched_dispatch_can_render(ctx):
+    """Images of unequal extent are no chain at all (a batched dispatch needs equal extents, single dispatches do not); a scratch
+    budget shorter than the chain cuts it into several batched dispatches; a batched dispatch that is refused is replayed one
+    dispatch at a time.  The images are those of the plain loop every time."""
+    from path_tracer_amd import hip
+    b = make_bundle("atrium", 20_000, 64, 48, max_bounce=3)
+    gs = hip.GpuScene(ctx, b, b["nodes"], b["flat"], b["meta"])
+    want, _, _ = oracle_frames(b, 6, use_flat=True, materials=gs.materials_host, textures=gs.texture_table)
+
+    def generate_launches(body):
+        ctx.profile_read(reset=True)
+        ctx.profile_enable(True)
+        try:
+            body()
+        finally:
+            ctx.profile_enable(False)
+        return ctx.profile_read(reset=True)["wavefront.generate"]["launches"]
+
+    # (1) a taller accumulation image: every dispatch runs on its own
+    tall = (ctx.create_2d_texture(64, 48, hip.FORMAT_RGBA32_SFLOAT), ctx.create_2d_texture(64, 56, hip.FORMAT_RGBA32_SFLOAT))
+    loop = hip.FrameLoop(ctx, gs, 64, 48, "compute", textures=tall)
+    ctx.set_option("dispatch.coalesce", 8)
+    try:
+        n = generate_launches(lambda: [loop.frame() for _ in range(6)] and ctx.flush())
+        assert n == 6
+        assert np.array_equal(loop.latest().read()[:48], want)
+        # (2) a budget of 1 MB holds 64 x 48 x 132 B twice: chains of two
+        ctx.set_option("dispatch.coalesce_scratch_mb", 1)
+        loop = hip.FrameLoop(ctx, gs, 64, 48, "compute")
+        n = generate_launches(lambda: [loop.frame() for _ in range(6)] and ctx.flush())
+        assert n == 3
+        assert np.array_equal(loop.latest().read(), want)
+        ctx.set_option("dispatch.coalesce_scratch_mb", 8192)
+        # (3) the batched dispatch fails: the six frames still arrive, one dispatch each
+        ctx.set_option("debug.refuse_batches", 1)
+        loop = hip.FrameLoop(ctx, gs, 64, 48, "compute")
+        n = generate_launches(lambda: [loop.frame() for _ in range(6)] and ctx.flush())
+        assert n == 6
+        last, other = _both_images(loop)
+        assert np.array_equal(last, want)
+        want5, _, _ = oracle_frames(b, 5, use_flat=True, materials=gs.materials_host, textures=gs.texture_table)
+        assert np.array_equal(other, want5)
+    finally:
+        ctx.set_option("debug.refuse_batches", 0)
+        ctx.set_option("dispatch.coalesce_scratch_mb", 8192)
+        ctx.set_option("dispatch.coalesce", 1)
+    for t in tall:
+        t.destroy()
+
+
 def test_a_dispatch_that_cannot_run_is_refused_at_once_also_when_dispatches_are_held_back(ctx):
     from path_tracer_amd import hip
     b = make_bundle("tiny", 0, 32, 24, max_bounce=2)
