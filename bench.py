@@ -49,10 +49,29 @@ def log(rank, *a):
         print("[bench]", *a, file=sys.stderr, flush=True)
 
 
+def load_or_generate(args, rank):
+    """The scene of the line: the reference's own asset when its files are there AND are the objects its Git-LFS pointers name
+    (path_tracer_amd/assets.py), through the glTF loader; the procedural stand-in otherwise.  sc["data"] says which."""
+    from path_tracer_amd import assets, host, scenes
+    path, report = assets.probe(getattr(args, "models_dir", None) or os.path.join(ROOT, "models"), args.scene)
+    if path is None:
+        log(rank, f"real assets: not used ({report.get('reason')}); synthetic scene")
+        sc = scenes.generate(args.scene, args.triangles, texture_size=args.texture_size)
+        sc["data"] = "synthetic"
+        return sc
+    sc = host.gltf_load(path, apply_transforms=True)
+    folder = assets.SCENES[args.scene][0]
+    # the reference's one camera (src/main.cpp:219-223)
+    sc.update(kind=f"{folder} (the reference's asset, {report['files_verified']} files sha256-verified against its Git-LFS pointers)", data="real",
+              camera=dict(pos=[13.0, 2.0, -3.0], target=[0.0, 0.0, 0.0], v_fov=90.0, aperture=0.1, focus=10.0))
+    log(rank, f"real assets: {path} ({report['files_verified']} files verified)")
+    return sc
+
+
 def build_scene(args, rank):
     from path_tracer_amd import host, scenes
     t0 = time.time()
-    sc = scenes.generate(args.scene, args.triangles, texture_size=args.texture_size)
+    sc = load_or_generate(args, rank)
     instanced = getattr(args, "instances", "1x1") not in ("", "1x1")
     if instanced:
         # the 10^8-triangle class: translated copies of the scene on a grid, one flat scene in the 4-word index layout.
@@ -217,10 +236,13 @@ def make_parser():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--bounces", type=int, default=4)
     ap.add_argument("--texture-size", type=int, default=512)
+    ap.add_argument("--models-dir", default=None, help="where the reference's real scene files would be (default: models/ next to this file); used only when "
+                                                       "every file matches the sha256 of the reference's Git-LFS pointer, else the procedural stand-in is rendered")
     ap.add_argument("--instances", default="1x1", help="NXxNZ translated copies of the scene on a grid (e.g. 6x6 of the default scene = 10^8 triangles)")
     ap.add_argument("--two-level", action="store_true", help="with --instances: keep ONE copy of the scene and its tree, and place it through a top-level tree")
     ap.add_argument("--pipeline", default="compute", choices=["compute", "compute.megakernel", "compute.wavefront"])
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="budget of the CPU baseline leg (0 = skip)")
+    ap.add_argument("--skip-parity", action="store_true", help="leave out the comparison of the timed region's image with the CPU oracle (a few seconds of host time)")
     ap.add_argument("--bvh", default="host", choices=["host", "gpu", "auto"],
                     help="host: binned-SAH flattener (default); gpu: ptr_bvh_build_flat; auto: only the reference's buffers are uploaded and "
                          "\"bvh.auto_flatten\" lets the first dispatch build and bind the layout")
@@ -261,7 +283,8 @@ def result_line(args, sc, W, H, world, tiles, elapsed, t1_elapsed, rays_total, s
     node_bytes, tri_bytes = (64, 64) if wavefront else (32, 48)
     algo_bytes = node_bytes * stats["nodes"] + tri_bytes * stats["triangles"]  # this rank's launches over all timed steps
     achieved = algo_bytes / (k["total_ms"] * 1e-3) / 1e9 if k["total_ms"] > 0 else 0.0
-    line_workload = (f"{sc['kind']} (Bistro-Exterior-class procedural stand-in), {sc['triangles'].shape[0] * int(sc.get('copies', 1))} triangles, "
+    stand_in = "" if sc.get("data") == "real" else " (Bistro-Exterior-class procedural stand-in)"
+    line_workload = (f"{sc['kind']}{stand_in}, {sc['triangles'].shape[0] * int(sc.get('copies', 1))} triangles, "
                      f"{W}x{H}, 1 spp per step, max_bounce {args.bounces}, min_bounce 1, dof off")
     ks = solo.get(dominant, dict(launches=0, total_ms=0.0))
     solo_bytes = algo_bytes * ks["launches"] / max(1, k["launches"]) if k["launches"] else algo_bytes
@@ -549,7 +572,7 @@ def main():
                 gpu.instance_buffer = ctx.create_buffer(sc["flat_instances"].nbytes)
                 gpu.instance_buffer.write(sc["flat_instances"])
                 ctx.bind_instances(gpu_flat, gpu.instance_buffer)
-            flat = gpu_flat.read(np.uint8) if args.cpu_seconds > 0 else flat
+            flat = gpu_flat.read(np.uint8) if (args.cpu_seconds > 0 or not args.skip_parity) else flat
             log(rank, f"GPU BVH build: {build_times['gpu_build_device_ms']:.1f} ms on the device, {build_times['gpu_build_wall_s'] * 1e3:.1f} ms wall")
         W, H = args.width, args.height
         img_a = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
@@ -756,7 +779,7 @@ def main():
                                                     "coalesced": {"ms_per_step": coalesced_ms, "value": rays_total / (coalesced_ms * 1e-3 * args.steps) / 1e6, "unit": "Mrays/s",
                                                                   "dispatch.coalesce": loop.samples_per_dispatch, "image_equals_timed_region": coalesced_equal,
                                                                   "note": "the same K single-sample dispatches with \"dispatch.coalesce\" set: the library holds them back and renders them as batched dispatches"}}
-            if timed_image is not None and args.pipeline != "compute.megakernel" and flat is not None and args.cpu_seconds > 0:
+            if timed_image is not None and args.pipeline != "compute.megakernel" and flat is not None and not args.skip_parity:
                 line["parity_check"] = parity_check(sc, nodes, flat, meta, gpu, timed_image, args.steps)
                 log(rank, "parity_check:", line["parity_check"])
             else:

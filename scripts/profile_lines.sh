@@ -1,4 +1,5 @@
 #!/bin/bash
+# (--cpu-seconds 0 leaves the CPU baseline leg out; every line still carries parity_check: its image against the oracle on four bands.)
 # The secondary bench lines kept under profiles/: GPU-built tree, 25 M / 10^8 triangles written out, 10^8 triangles as placed copies.
 set -e
 cd "$GRAFT_REPO_ROOT"

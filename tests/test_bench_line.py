@@ -117,3 +117,35 @@ def test_traffic_is_reported_only_for_the_workload_it_was_measured_on():
     if recorded > 1:  # one sample per dispatch is another regime (drain tails per sample): not derived from batched launches
         assert bench.pmc_traffic("wavefront.extend", t["workload"], 1)[0] is None
     assert bench.pmc_traffic("wavefront.extend", "another scene", recorded)[0] is None
+
+
+def test_real_assets_are_used_only_when_they_are_the_objects_the_pointers_name(tmp_path):
+    """The probe behind the line's `data` field: a folder whose .gltf, buffer and image all have the size and sha256 the table
+    holds is accepted; one changed byte, a missing file or a Git-LFS pointer in place of the file is not.  With the reference's
+    own table nothing in this repository qualifies (its checkout holds pointers only), so bench.py renders the stand-in."""
+    import hashlib
+    sys.path.insert(0, os.path.join(bench.ROOT, "path-tracer_amd", "python"))
+    from path_tracer_amd import assets
+    folder = tmp_path / "BistroExterior"
+    folder.mkdir()
+    files = {"BistroExterior.gltf": json.dumps({"asset": {"version": "2.0"}, "buffers": [{"uri": "BistroExterior.bin", "byteLength": 12}],
+                                                "images": [{"uri": "a.png"}]}).encode(),
+             "BistroExterior.bin": bytes(range(12)), "a.png": b"\x89PNG not really"}
+    table = {}
+    for name, data in files.items():
+        (folder / name).write_bytes(data)
+        table[os.path.join("BistroExterior", name)] = dict(sha256=hashlib.sha256(data).hexdigest(), size=len(data))
+    path, report = assets.probe(str(tmp_path), "street_exterior", table)
+    assert path == str(folder / "BistroExterior.gltf") and report["used"] and report["files_verified"] == 3
+    (folder / "a.png").write_bytes(b"\x89PNG not reallY")                      # same size, another object
+    assert assets.probe(str(tmp_path), "street_exterior", table)[0] is None
+    (folder / "a.png").unlink()
+    assert assets.probe(str(tmp_path), "street_exterior", table)[0] is None
+    (folder / "BistroExterior.gltf").write_bytes(b"version https://git-lfs.github.com/spec/v1\noid sha256:00\nsize 1\n")
+    assert "pointer" in assets.probe(str(tmp_path), "street_exterior", table)[1]["reason"]
+    # the table generated from the reference's pointer files names its three scenes
+    with open(assets.TABLE) as f:
+        real = json.load(f)["files"]
+    assert real["sponza/Sponza.gltf"] == dict(sha256="e17c14edbc06b757dafcfed99f8815af9c5f5d9f9de3f0bc7740c37e68e0d829", size=212504)
+    assert real["BistroExterior/BistroExterior.bin"]["size"] == 130333472
+    assert assets.probe(os.path.join(bench.ROOT, "models"), "street_exterior")[0] is None

@@ -209,6 +209,29 @@ def test_c5_100m_triangles_as_36_placed_copies_one_rank_of_eight(ctx):
     assert_bands_equal(img, acc, bands, "C5, rank 5 of 8")
 
 
+def test_c5_class_25m_triangles_written_out_multi_gb_tree(ctx):
+    """The multi-GB-tree case of C5 with the tree written out instead of placed: 3 x 3 copies of the benchmark's scene as ONE
+    flat scene in the 4-word index layout (25.2 M triangles: 1.6 GB of triangle records + 0.4 GB of nodes resident in HBM, far
+    past L2 + Infinity Cache), 1920x1080, max_bounce 4, two samples, against the oracle walking the same layout on six row
+    bands, bit for bit."""
+    import os
+    import sys
+    from path_tracer_amd import hip
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    args = bench.make_parser().parse_args(["--instances", "3x3"])
+    sc, nodes, flat, meta, _ = bench.build_scene(args, rank=1)
+    assert sc["triangles"].shape[0] == 9 * 2_796_540 and flat.nbytes > 1_900_000_000
+    b = dict(sc, nodes=nodes, flat=flat, meta=meta, width=args.width, height=args.height)
+    gs = hip.GpuScene(ctx, b, nodes, flat, meta)
+    frames = 2
+    img, _, _, _ = gpu_frames(ctx, b, frames, "compute", gpu_scene=gs)
+    bands = [(0, 3), (215, 218), (431, 434), (647, 650), (863, 866), (1077, 1080)]
+    want = oracle_bands(b, gs, bands, frames)
+    assert_bands_equal(img, want, bands, "25.2 M triangles written out")
+    assert float(img[..., :3].std()) > 0.05                              # a picture, not a constant
+
+
 def test_c5_placed_copies_sample_partition_vs_sequential(ctx):
     """C5's shape at a size the CPU can follow: a scene of placed copies, the samples dealt out to 4 ranks (four partitions of
     one context here), every rank's running mean linearised, summed (what the all-reduce does) and resolved.  The result is
