@@ -153,16 +153,21 @@ constexpr int32_t kTraversalDone = INT32_MIN;  // never a leaf reference: triang
 //   * TWO_LEVEL: the tree in fv.top is walked first; its leaves name placed copies of the tree in fv.  A lane that
 //     reaches one takes its ray into the object's space, stacks a marker and goes on at the object's root; when the
 //     marker pops, the world-space ray is read back from the queue.  Both trees share the lane's one stack.
-//     (Entering and leaving a copy each cost the lane a leaf turn.  Doing both where the reference becomes current, or as
-//     one repetition of an inner turn, was measured: 10 % slower -- the record and queue loads stall the whole wave
-//     inside its inner turn, and the extra live registers cost a resident wave.)
+//     Entering a copy costs the lane a leaf turn (the record's loads, the transform, three reciprocals); doing it where the
+//     reference becomes current, or as one repetition of an inner turn, was measured: 10 % slower -- the record loads stall
+//     the whole wave inside its inner turn, and the extra live registers cost a resident wave.  Leaving costs nothing of
+//     the kind: the world-space ray and its reciprocals wait in nine words of LDS per lane and come back where the marker
+//     is popped (re-reading the queue there, and taking a leaf turn for it, made the placed copies 37 % slower than the
+//     same copies written out).
 template <bool STATS, int REFILL, int LEAF_WEIGHT, bool LEAF_ALL, int INNER_REPS, bool TWO_LEVEL>
 __global__ __launch_bounds__(kExtendThreads, TWO_LEVEL ? 6 : 4) void ptr_wf_extend(FlatView fv, WavefrontScratch w, uint32_t gen, uint32_t slot_b,
                                                                 unsigned long long* stats) {
-    __shared__ int32_t lds_stack[(kExtendThreads / 64) * kStackLds * 64];
+    constexpr uint32_t kWaveWords = kStackLds * 64u + (TWO_LEVEL ? 9u * 64u : 0u);   // a wave's stacks, then its lanes' world-space rays
+    __shared__ int32_t lds_stack[(kExtendThreads / 64) * kWaveWords];
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave_in_block = threadIdx.x >> 6;
-    int32_t* my_lds = lds_stack + wave_in_block * kStackLds * 64 + lane;
+    int32_t* my_lds = lds_stack + wave_in_block * kWaveWords + lane;
+    float* my_world = (float*)(my_lds + kStackLds * 64u);   // TWO_LEVEL: o, d, 1/d of the ray outside the copy the lane is in
     int32_t* my_spill = w.stack_spill + (size_t)(blockIdx.x * (kExtendThreads / 64) + wave_in_block) * w.spill_entries * 64 + lane;
 
     const uint32_t count = w.counters[slot_b];
@@ -187,6 +192,24 @@ __global__ __launch_bounds__(kExtendThreads, TWO_LEVEL ? 6 : 4) void ptr_wf_exte
     uint32_t sp = 0u;
     uint32_t alone_turns = 0u;                  // wave-uniform: iterations with a single busy lane and nothing left to fetch
     int lone_lane = -1;
+    constexpr int32_t kLeaveMarker = ~(int32_t)(kInstanceTag | kLeaveInstance);
+    // The next pending reference becomes current.  A marker on the way means the copy the lane was in is done: the lane is
+    // back at the top level with the ray it had there.
+    auto next_pending = [&]() {
+        if (sp == 0u) { cur = kTraversalDone; return; }
+        sp--;
+        cur = stack_pop(my_lds, my_spill, sp);
+        if (TWO_LEVEL && cur == kLeaveMarker) {
+            o = mk3(my_world[0], my_world[64], my_world[128]);
+            d = mk3(my_world[192], my_world[256], my_world[320]);
+            inv = mk3(my_world[384], my_world[448], my_world[512]);
+            neg_x = (as_u32(inv.x) >> 31) != 0u; neg_y = (as_u32(inv.y) >> 31) != 0u; neg_z = (as_u32(inv.z) >> 31) != 0u;
+            cur_inst = -1;
+            if (sp == 0u) { cur = kTraversalDone; return; }
+            sp--;
+            cur = stack_pop(my_lds, my_spill, sp);
+        }
+    };
 
     for (;;) {
         const unsigned long long idle = __ballot(slot == kInvalidPixel);
@@ -273,45 +296,36 @@ __global__ __launch_bounds__(kExtendThreads, TWO_LEVEL ? 6 : 4) void ptr_wf_exte
                     if (k2 < inf) { if (sp < kStackLds) my_lds[sp * 64u] = r2; else my_spill[(sp - kStackLds) * 64u] = r2; sp++; }
                 }
                 cur = r0;
-            } else if (sp == 0u) {
-                cur = kTraversalDone;
             } else {
-                sp--;
-                cur = stack_pop(my_lds, my_spill, sp);
+                next_pending();
             }
         }
 
         if (leaf_turn && at_leaf) {
             uint32_t ref = (uint32_t)~cur;
             if (TWO_LEVEL && (ref & kInstanceTag) != 0u) {
+                // a placed copy: the ray goes into the object's space (the one it has out here is kept in LDS), a marker goes
+                // on the stack, and the walk goes on at the object's root
                 const uint32_t index = ref & ~kInstanceTag;
-                if (index == kLeaveInstance) {
-                    // the object is done: back to the world-space ray, then on with the top level
-                    const float4 ro = w.ray_o[gen][slot], rd = w.ray_d[gen][slot];
-                    o = mk3(ro.x, ro.y, ro.z);
-                    d = mk3(rd.x, rd.y, rd.z);
-                    cur_inst = -1;
-                    if (sp == 0u) {
-                        cur = kTraversalDone;
-                    } else {
-                        sp--;
-                        cur = stack_pop(my_lds, my_spill, sp);
-                    }
-                } else {
-                    const float4* rec = fv.top.records + 4 * (size_t)index;
-                    const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2];
-                    const int32_t object_root = __float_as_int(rec[3].x);
-                    const f3 wo = o, wd = d;
-                    o = xform_point(r0, r1, r2, wo);
-                    d = xform_dir(r0, r1, r2, wd);
-                    cur_inst = (int32_t)index;
-                    const int32_t marker = ~(int32_t)(kInstanceTag | kLeaveInstance);
-                    if (sp < kStackLds) my_lds[sp * 64u] = marker; else my_spill[(sp - kStackLds) * 64u] = marker;
-                    sp++;
-                    cur = object_root;
+                const float4* rec = fv.top.records + 4 * (size_t)index;
+                const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2];
+                const int32_t object_root = __float_as_int(rec[3].x);
+                const f3 wo = o, wd = d;
+                my_world[0] = wo.x; my_world[64] = wo.y; my_world[128] = wo.z;
+                my_world[192] = wd.x; my_world[256] = wd.y; my_world[320] = wd.z;
+                my_world[384] = inv.x; my_world[448] = inv.y; my_world[512] = inv.z;
+                o = xform_point(r0, r1, r2, wo);
+                d = xform_dir(r0, r1, r2, wd);
+                cur_inst = (int32_t)index;
+                if (sp < kStackLds) my_lds[sp * 64u] = kLeaveMarker; else my_spill[(sp - kStackLds) * 64u] = kLeaveMarker;
+                sp++;
+                cur = object_root;
+                // a copy that is only moved, not turned or scaled, leaves the direction as it is, bit for bit: its reciprocals
+                // (three correctly rounded divisions) are the ones the lane already has
+                if (as_u32(d.x) != as_u32(wd.x) || as_u32(d.y) != as_u32(wd.y) || as_u32(d.z) != as_u32(wd.z)) {
+                    inv = mk3(rcp(d.x), rcp(d.y), rcp(d.z));
+                    neg_x = (as_u32(inv.x) >> 31) != 0u; neg_y = (as_u32(inv.y) >> 31) != 0u; neg_z = (as_u32(inv.z) >> 31) != 0u;
                 }
-                inv = mk3(rcp(d.x), rcp(d.y), rcp(d.z));
-                neg_x = (as_u32(inv.x) >> 31) != 0u; neg_y = (as_u32(inv.y) >> 31) != 0u; neg_z = (as_u32(inv.z) >> 31) != 0u;
             } else {
             // LEAF_ALL: every triangle of the lane's leaf in this turn; otherwise ONE triangle, the rest of the leaf
             // stays encoded in `cur` for the next leaf turn (lanes with short leaves get back to inner nodes sooner)
@@ -339,14 +353,7 @@ __global__ __launch_bounds__(kExtendThreads, TWO_LEVEL ? 6 : 4) void ptr_wf_exte
                 ref = ((first + 1u) << 2) | (remaining - 1u);
                 if (!LEAF_ALL) break;
             }
-            if (ref != 0xffffffffu) {
-                cur = ~(int32_t)ref;
-            } else if (sp == 0u) {
-                cur = kTraversalDone;
-            } else {
-                sp--;
-                cur = stack_pop(my_lds, my_spill, sp);
-            }
+            if (ref != 0xffffffffu) cur = ~(int32_t)ref; else next_pending();
             }
         }
 
@@ -368,7 +375,7 @@ __global__ __launch_bounds__(kExtendThreads, TWO_LEVEL ? 6 : 4) void ptr_wf_exte
     // takes the world-space ray into that copy's space itself, and an instance leaf appends the object's root under
     // the copy's number; the marker the single-lane walk keeps on its stack is not needed.
     if (!STATS && lone_lane >= 0) {
-        int32_t* list = lds_stack + wave_in_block * kStackLds * 64;   // references, linear
+        int32_t* list = lds_stack + wave_in_block * kWaveWords;       // references, linear
         constexpr uint32_t kListMax = TWO_LEVEL ? kStackLds * 32 : kStackLds * 64;
         int32_t* list_copy = list + kListMax;                         // TWO_LEVEL: the copy of each entry
         // everything about the ray is the same in all lanes from here on: kept in scalar registers
@@ -386,7 +393,7 @@ __global__ __launch_bounds__(kExtendThreads, TWO_LEVEL ? 6 : 4) void ptr_wf_exte
         const int32_t copy_of_l = lane_value(cur_inst, L);
         const uint32_t depth = lane_value(sp, L);
         int32_t top = lane_value(cur, L);
-        constexpr int32_t kMarker = ~(int32_t)(kInstanceTag | kLeaveInstance);
+        constexpr int32_t kMarker = kLeaveMarker;
         // gather the lane-interleaved stack of lane L, then lay it out linearly (at most kStackMax + 3 entries: four per lane)
         const int32_t* spill_of_l = my_spill - lane + L;
         int32_t held[4];
