@@ -96,6 +96,17 @@ int ptr_bvh_bind_flat(ptr_ctx* ctx, ptr_handle threaded_nodes, ptr_handle flat);
  * copy * triangle_count + primitive.  instances = 0 removes the association.  The megakernel path does not instance. */
 int ptr_bvh_bind_instances(ptr_ctx* ctx, ptr_handle flat, ptr_handle instances);
 
+/* Sphere leaves.  The reference's first scene was made of spheres: shaders/include/ray.h:105-135 still holds hit_sphere, its call
+ * site in hit_node is commented out (ray.h:173-177, `bufs.geometry.spheres[primitive_id]`), and so are the lines that would give
+ * a hit its point and outward normal (ray.h:127-132).  This binds `count` records of the shader's `sphere` struct
+ * (compute.comp:31-36: vec4 position, the 48-byte material, float radius, 12 bytes of padding = 80 bytes) to a flattened layout
+ * whose primitive array holds sphere records beside its triangles (bvh::flatten(..., spheres) / ptrh_bvh_flatten_spheres).  A
+ * sphere is tested with hit_sphere against the ray shortened to the closest hit so far; a hit is shaded with the frame those
+ * commented lines describe -- the point on the ray, the normal (point - centre) / radius -- texture coordinates (0, 0) and the
+ * material embedded in the record; a captured primitive id reads 0x40000000 | sphere index.  spheres = 0 removes the
+ * association.  Wavefront pipeline only, and not together with placed copies. */
+int ptr_bvh_bind_spheres(ptr_ctx* ctx, ptr_handle flat, ptr_handle spheres, uint32_t count);
+
 /* ---- dispatch: ComputeRenderpass::execute -> vkCmdPushConstants(64 B) + vkCmdDispatch
  *      (src/compute-renderpass.cpp:51-63, src/vk-api.cpp:1090-1092,1171-1177).
  *      kernel: the reference's shader names, "compute" (shaders/compute.comp) or "tonemapping"

@@ -30,6 +30,11 @@ int32_t ptrh_bvh_visit_ranks(const void* nodes, int64_t node_count, int64_t prim
  * ranks may be NULL (rank = primitive index); threads 0 = automatic. */
 int32_t ptrh_bvh_flatten(const float* positions, int64_t n, const int32_t* ranks, uint32_t threads, void** blob_out,
                          uint64_t* size_out);
+/* The same with sphere leaves: `spheres` holds sphere_count records of 4 floats (centre, radius) -- the primitive of the
+ * reference's hit_sphere (shaders/include/ray.h:105-135; its call site in hit_node is commented out, ray.h:173-177).
+ * Sphere s reports primitive 0x40000000 | s; n may be 0. */
+int32_t ptrh_bvh_flatten_spheres(const float* positions, int64_t n, const int32_t* ranks, const float* spheres, int64_t sphere_count, uint32_t threads,
+                                 void** blob_out, uint64_t* size_out);
 /* bvh::flatten_instances(): the top level over `instance_count` placed copies of one flattened tree -- an extension,
  * the reference has no instancing (its scene is one triangle soup, src/scene.cpp:84-176).  object_blob is
  * ptrh_bvh_flatten()'s (or ptr_bvh_build_flat()'s) output; object_to_world holds 12 floats per instance, the three

@@ -403,9 +403,12 @@ typedef struct {
 typedef struct {
     float p0[3]; int32_t rank;
     float e1[3]; int32_t primitive_id;
-    float e2[3]; int32_t pad0;
+    float e2[3]; int32_t kind;   /* 0: triangle; 1: sphere -- p0 = centre, e1[0] = radius, primitive_id = FLAT_SPHERE_TAG | index */
     float n[3];  int32_t pad1;
 } flat_tri_t;
+#define FLAT_KIND_SPHERE 1
+#define FLAT_SPHERE_TAG 0x40000000
+typedef struct { float position[4]; uint8_t mat[48]; float radius; float pad[3]; } sphere_t; /* compute.comp:31-36, 80 bytes */
 
 #define FLAT_PAD 1.0000002384185791015625f
 #define FLAT_EMPTY_CHILD INT32_MIN
@@ -516,6 +519,17 @@ static void flat_walk(const void* blob, int32_t root, v3 o, v3 d, float min_t, i
             for (uint32_t k = 0; k < count; k++) {
                 const flat_tri_t* tr = &tris[first + k];
                 s->n_tris++;
+                if (tr->kind == FLAT_KIND_SPHERE) {
+                    /* a sphere leaf: hit_sphere (ray.h:105-135) against the ray shortened to the best hit so far, as the commented
+                     * call site in hit_node would run it (ray.h:173-177); a NaN distance is no hit, ties go by rank like triangles */
+                    ray_t sr; sr.origin = o; sr.direction = d; sr.min_t = min_t; sr.max_t = s->best_t;
+                    float ts;
+                    if (!hit_sphere(V3(tr->p0[0], tr->p0[1], tr->p0[2]), tr->e1[0], &sr, &ts) || is_nan(ts)) continue;
+                    if (s->hit && ts == s->best_t && (inst < s->best_inst || (inst == s->best_inst && tr->rank < s->best_rank))) continue;
+                    s->hit = 1; s->best_t = ts; s->best_u = 0.0f; s->best_v = 0.0f; s->best_rank = tr->rank; s->best_prim = tr->primitive_id;
+                    s->best_inst = inst;
+                    continue;
+                }
                 v3 e1 = V3(tr->e1[0], tr->e1[1], tr->e1[2]), e2 = V3(tr->e2[0], tr->e2[1], tr->e2[2]);
                 v3 n = V3(tr->n[0], tr->n[1], tr->n[2]);
                 v3 ov = sub3(o, V3(tr->p0[0], tr->p0[1], tr->p0[2]));
@@ -572,6 +586,19 @@ static int hit_node_flat(const orc_frame* f, ray_t r, hit_t* info, orc_counters*
     float o[3] = { r.origin.x, r.origin.y, r.origin.z }, d[3] = { r.direction.x, r.direction.y, r.direction.z };
     int32_t inst = -1;
     if (!orc_closest_hit_two_level(f->flat_bvh, f->flat_instances, o, d, r.min_t, r.max_t, &prim, &inst, &t, bary, c)) return 0;
+    if (prim & FLAT_SPHERE_TAG) {
+        /* the frame the reference's hit_sphere had in mind (its commented lines, ray.h:127-132): the point on the ray and the
+         * outward normal (point - centre) / radius */
+        const sphere_t* sp = &((const sphere_t*)f->spheres)[prim & ~FLAT_SPHERE_TAG];
+        info->t = t;
+        info->barycentrics = V3(bary[0], bary[1], bary[2]);
+        info->point = add3(r.origin, scale3(r.direction, t));
+        v3 out = sub3(info->point, V3(sp->position[0], sp->position[1], sp->position[2]));
+        info->geometry_normal = V3(out.x / sp->radius, out.y / sp->radius, out.z / sp->radius);
+        info->instance = inst;
+        info->primitive_id = (uint32_t)prim;
+        return 1;
+    }
     uint32_t idx[4];
     decode_triangle_indices(f, (uint32_t)prim, idx);
     v3 p0 = load3(f->positions, idx[0]), p1 = load3(f->positions, idx[1]), p2 = load3(f->positions, idx[2]);
@@ -657,13 +684,23 @@ static v3 ray_color(const orc_frame* f, const meta_t* m, ray_t r, uint32_t seed,
 
         v3 v = neg3(r.direction);
 
-        uint32_t idx[4];
-        decode_triangle_indices(f, info.primitive_id, idx);
-        v3 nrm[3] = { load3(f->normals, idx[0]), load3(f->normals, idx[1]), load3(f->normals, idx[2]) };
-        v2 tuv[3] = { { f->uvs[idx[0] * 2], f->uvs[idx[0] * 2 + 1] },
-                      { f->uvs[idx[1] * 2], f->uvs[idx[1] * 2 + 1] },
-                      { f->uvs[idx[2] * 2], f->uvs[idx[2] * 2 + 1] } };
-        const material_t* mat = &materials[idx[3]];
+        v3 nrm[3];
+        v2 tuv[3];
+        const material_t* mat;
+        if (f->use_flat && (info.primitive_id & FLAT_SPHERE_TAG)) {
+            /* a sphere: the outward normal at all three "vertices", texture coordinates (0, 0), the material the sphere record embeds */
+            nrm[0] = nrm[1] = nrm[2] = info.geometry_normal;
+            tuv[0].x = tuv[0].y = tuv[1].x = tuv[1].y = tuv[2].x = tuv[2].y = 0.0f;
+            mat = (const material_t*)((const sphere_t*)f->spheres)[info.primitive_id & ~FLAT_SPHERE_TAG].mat;
+        } else {
+            uint32_t idx[4];
+            decode_triangle_indices(f, info.primitive_id, idx);
+            nrm[0] = load3(f->normals, idx[0]); nrm[1] = load3(f->normals, idx[1]); nrm[2] = load3(f->normals, idx[2]);
+            tuv[0].x = f->uvs[idx[0] * 2]; tuv[0].y = f->uvs[idx[0] * 2 + 1];
+            tuv[1].x = f->uvs[idx[1] * 2]; tuv[1].y = f->uvs[idx[1] * 2 + 1];
+            tuv[2].x = f->uvs[idx[2] * 2]; tuv[2].y = f->uvs[idx[2] * 2 + 1];
+            mat = &materials[idx[3]];
+        }
 
         v2 uv = interp2(tuv, info.barycentrics);
         v3 shading_normal = normalize3(interp3(nrm, info.barycentrics));

@@ -79,6 +79,9 @@ typedef struct {
                                     partition over several GPUs, where a GPU's k-th frame draws global sample (k-1)*world+rank+1 */
     const void* flat_instances;  /* optional top level over placed copies of flat_bvh (header|nodes|instance records); used with
                                     use_flat.  Captured primitive ids then read instance * triangle_count + primitive. */
+    const void* spheres;         /* optional: the reference's `sphere` records (compute.comp:31-36: vec4 position, 48-byte material,
+                                    radius, 12 bytes of padding = 80 bytes) that the sphere leaves of flat_bvh name; used with use_flat */
+    uint32_t sphere_count;
 } orc_frame;
 
 /* compute.comp main() over the rows [y0, y1) of the dispatch, `threads` worker threads. */

@@ -33,7 +33,7 @@ class Frame(C.Structure):
                 ("textures", C.POINTER(Texture)), ("texture_count", C.c_uint32), ("accumulation", Image),
                 ("output", Image), ("aov_prim", C.c_void_p), ("aov_t", C.c_void_p), ("flat_bvh", C.c_void_p),
                 ("use_flat", C.c_int32), ("index_words", C.c_uint32), ("seed_sample_index", C.c_uint32),
-                ("flat_instances", C.c_void_p)]
+                ("flat_instances", C.c_void_p), ("spheres", C.c_void_p), ("sphere_count", C.c_uint32)]
 
 
 def build(force=False):
@@ -111,6 +111,9 @@ class OracleScene:
         self.textures = [None if t is None else np.ascontiguousarray(t, dtype=np.uint8) for t in arrays["textures"]]
         self.flat = None if arrays.get("flat") is None else np.ascontiguousarray(arrays["flat"], dtype=np.uint8)
         self.instances = None if arrays.get("flat_instances") is None else np.ascontiguousarray(arrays["flat_instances"], dtype=np.uint8)
+        # sphere leaves: the reference's 80-byte `sphere` records (compute.comp:31-36) the flattened layout's sphere leaves name
+        self.spheres = None if arrays.get("sphere_records") is None else np.ascontiguousarray(arrays["sphere_records"])
+        assert self.spheres is None or self.spheres.nbytes % 80 == 0
         self._tex = (Texture * max(1, len(self.textures)))()
         for i, t in enumerate(self.textures):
             if t is not None:
@@ -150,6 +153,9 @@ class OracleScene:
             f.use_flat = 1
             if self.instances is not None:
                 f.flat_instances = self.instances.ctypes.data
+            if self.spheres is not None:
+                f.spheres = self.spheres.ctypes.data
+                f.sphere_count = self.spheres.nbytes // 80
         return f
 
     def render(self, acc, out, rows=None, threads=None, aov=None, use_flat=False):

@@ -81,6 +81,7 @@ int dispatch_or_hold(ptr_ctx* c, const uint8_t constants[64], uint32_t gx, uint3
         p.reads[7] = c->buffers[handles[1]].flat;
         const BufferRec* flat = find_buffer(c, p.reads[7]);
         p.reads[8] = flat ? flat->instances : 0;
+        p.reads[9] = flat ? flat->spheres : 0;
     }
     if (p.count >= (uint32_t)c->opt_coalesce) return flush_pending(c);
     return PTR_OK;

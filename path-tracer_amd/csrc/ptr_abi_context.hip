@@ -282,7 +282,7 @@ int ptr_buffer_destroy(ptr_ctx* c, ptr_handle h) {
     }
     PTR_HIP_CHECK(c, hipFree(b->ptr));
     *b = BufferRec();
-    for (auto& o : c->buffers) { if (o.flat == h) o.flat = 0; if (o.instances == h) o.instances = 0; }
+    for (auto& o : c->buffers) { if (o.flat == h) o.flat = 0; if (o.instances == h) o.instances = 0; if (o.spheres == h) { o.spheres = 0; o.sphere_count = 0; } }
     if (c->capture == h) c->capture = 0;
     return PTR_OK;
 }

@@ -81,8 +81,12 @@ int ensure_shade_records(ptr_ctx* c, const uint64_t addr[7], const ptr_handle ha
 // bad scene fails the dispatch instead of faulting the device.
 int validate_scene(ptr_ctx* c, const uint64_t addr[7], const ptr_handle handles[7], const ptr::SceneView& sv, BufferRec* flat_buf, bool wavefront, bool lookup_only = false) {
     if (!c->opt_validate) return PTR_OK;
-    uint64_t key[16] = {};
+    uint64_t key[19] = {};
     for (int i = 1; i < 7; i++) { key[i - 1] = addr[i]; key[5 + i] = c->buffers[handles[i]].generation; }
+    BufferRec* sphere_buf = wavefront && flat_buf && flat_buf->spheres ? find_buffer(c, flat_buf->spheres) : nullptr;
+    key[16] = sphere_buf ? (uint64_t)flat_buf->spheres : 0;
+    key[17] = sphere_buf ? sphere_buf->generation : 0;
+    key[18] = sphere_buf ? flat_buf->sphere_count : 0;
     key[12] = flat_buf ? flat_buf->generation : 0;
     key[13] = (uint64_t)c->opt_index_words | (wavefront ? 16u : 0u);
     BufferRec* top_buf = wavefront && flat_buf && flat_buf->instances ? find_buffer(c, flat_buf->instances) : nullptr;
@@ -112,7 +116,7 @@ int validate_scene(ptr_ctx* c, const uint64_t addr[7], const ptr_handle handles[
         fv = &view;
     }
     PTR_HIP_CHECK(c, ptr::launch_validate_scene(c->stream, sv, (uint32_t)triangles, (uint32_t)threaded, fv, fv ? flat_buf->flat_nodes : 0u,
-                                                fv ? flat_buf->flat_triangles : 0u, top_buf ? top_buf->top_nodes : 0u, c->d_validate));
+                                                fv ? flat_buf->flat_triangles : 0u, top_buf ? top_buf->top_nodes : 0u, sphere_buf ? flat_buf->sphere_count : 0u, c->d_validate));
     uint32_t out[4];
     PTR_HIP_CHECK(c, hipMemcpyAsync(out, c->d_validate, sizeof out, hipMemcpyDeviceToHost, c->stream));
     PTR_HIP_CHECK(c, hipStreamSynchronize(c->stream));
@@ -349,6 +353,13 @@ int dispatch_compute(ptr_ctx* c, const uint8_t constants[64], uint32_t gx, uint3
         sv.instance_count = fv.top.count;
         sv.object_triangles = flat_buf->flat_triangles;
     }
+    if (flat_buf->spheres) {   // sphere leaves: the records they name
+        const BufferRec* sb = find_buffer(c, flat_buf->spheres);
+        if (!sb) return fail(c, PTR_E_STATE, "spheres: the buffer bound with ptr_bvh_bind_spheres is gone");
+        if (top_buf) return fail(c, PTR_E_UNSUPPORTED, "spheres: a layout with sphere leaves cannot be instanced (ptr_bvh_bind_instances)");
+        sv.spheres = (const ptr::Sphere*)sb->ptr;
+        sv.sphere_count = flat_buf->sphere_count;
+    }
     if ((rc = validate_scene(c, k.addr, handles, sv, flat_buf, true, no_alloc))) return rc;
     if ((rc = ensure_shade_records(c, k.addr, handles, &sv, no_alloc))) return rc;
 
@@ -456,6 +467,7 @@ int dispatch_compute(ptr_ctx* c, const uint8_t constants[64], uint32_t gx, uint3
         for (int i = 0; i < 7; i++) slot.reads[i] = i == 0 ? 0 : handles[i];  // the metadata travels by value
         slot.reads[7] = bvh_buf->flat;
         slot.reads[8] = flat_buf->instances;
+        slot.reads[9] = flat_buf->spheres;
         c->next_slot = (c->next_slot + 1) % c->opt_frames_in_flight;
     }
     return PTR_OK;
@@ -495,10 +507,30 @@ int ptr_bvh_bind_instances(ptr_ctx* c, ptr_handle flat, ptr_handle instances) {
         if (!t) return fail(c, PTR_E_INVALID, "ptr_bvh_bind_instances: unknown instance buffer %u", instances);
         if (t->size < 64) return fail(c, PTR_E_INVALID, "ptr_bvh_bind_instances: instance buffer shorter than the 64-byte header");
         if (instances == flat) return fail(c, PTR_E_INVALID, "ptr_bvh_bind_instances: the instance buffer cannot be the flat buffer itself");
+        if (f->spheres) return fail(c, PTR_E_UNSUPPORTED, "ptr_bvh_bind_instances: this layout has sphere records bound (ptr_bvh_bind_spheres); a layout with sphere leaves cannot be instanced");
     }
     int rc = enter(c); if (rc) return rc;
     if ((rc = drain_frames(c))) return rc;
     f->instances = instances;
+    return PTR_OK;
+}
+
+int ptr_bvh_bind_spheres(ptr_ctx* c, ptr_handle flat, ptr_handle spheres, uint32_t count) {
+    if (!c) return PTR_E_INVALID;
+    BufferRec* f = find_buffer(c, flat);
+    if (!f) return fail(c, PTR_E_INVALID, "ptr_bvh_bind_spheres: unknown flat buffer %u", flat);
+    if (spheres != 0) {
+        BufferRec* s = find_buffer(c, spheres);
+        if (!s) return fail(c, PTR_E_INVALID, "ptr_bvh_bind_spheres: unknown sphere buffer %u", spheres);
+        if (count == 0 || count >= (1u << 29)) return fail(c, PTR_E_INVALID, "ptr_bvh_bind_spheres: 1 .. 2^29 - 1 spheres");
+        if (s->size < (size_t)count * sizeof(ptr::Sphere)) return fail(c, PTR_E_RANGE, "ptr_bvh_bind_spheres: the buffer holds fewer than %u records of %zu bytes", count, sizeof(ptr::Sphere));
+        if (spheres == flat) return fail(c, PTR_E_INVALID, "ptr_bvh_bind_spheres: the sphere buffer cannot be the flat buffer itself");
+        if (f->instances) return fail(c, PTR_E_UNSUPPORTED, "ptr_bvh_bind_spheres: this layout has placed copies bound (ptr_bvh_bind_instances); a layout with sphere leaves cannot be instanced");
+    }
+    int rc = enter(c); if (rc) return rc;
+    if ((rc = drain_frames(c))) return rc;
+    f->spheres = spheres;
+    f->sphere_count = spheres ? count : 0u;
     return PTR_OK;
 }
 

@@ -35,6 +35,8 @@ struct BufferRec {
     ptr::FlatView flat_view{};
     uint32_t flat_nodes = 0, flat_triangles = 0;  // counts from the parsed header
     ptr_handle instances = 0;      // on a flattened-layout buffer: the top level over its placed copies, if any
+    ptr_handle spheres = 0;        // on a flattened-layout buffer: the sphere records its sphere leaves name, if any
+    uint32_t sphere_count = 0;
     // "bvh.auto_flatten": `flat` was built by the library from the dispatch's own buffers, at these write generations of the
     // node / index / position buffers (a write to one of them makes the layout stale); or the build failed at them
     bool flat_is_auto = false, auto_failed = false;
@@ -99,7 +101,7 @@ struct ptr_ctx {
         uint64_t ready_epoch = 0;        // value of write_epoch when `ready` was last recorded
         ptr::WavefrontScratch scratch{};
         void* scratch_block = nullptr;
-        ptr_handle reads[9] = {};        // buffers the slot's last frame reads (hazard check of later writes)
+        ptr_handle reads[10] = {};       // buffers the slot's last frame reads (hazard check of later writes)
     };
     FrameSlot slots[kMaxFrameSlots];
     int next_slot = 0;
@@ -128,7 +130,7 @@ struct ptr_ctx {
         ptr::SceneMeta meta{};      // metadata of the first one (the others differ in sample_index only)
         uint32_t count = 0, gx = 0, gy = 0;
         int force = 0;
-        ptr_handle reads[9] = {};   // buffers the held-back dispatches will read (a write to one of them runs them first)
+        ptr_handle reads[10] = {};  // buffers the held-back dispatches will read (a write to one of them runs them first)
     };
     Pending pending;
     // the records, and what they were built from: addresses + write generations of indices / positions / normals / uvs
@@ -140,7 +142,7 @@ struct ptr_ctx {
     uint64_t write_epoch = 0;       // bumped by every buffer creation and write
     // verdicts of the scene-contents check, by what was checked (addresses + write generations); a few entries so that
     // dispatches alternating between scenes or pipelines do not re-check (and synchronise) every time
-    struct Validated { uint64_t key[16]; bool used = false; };
+    struct Validated { uint64_t key[19]; bool used = false; };
     Validated validated[4];
     int validated_next = 0;
     int opt_validate = 1;

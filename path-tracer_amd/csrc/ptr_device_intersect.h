@@ -6,9 +6,6 @@
 
 namespace ptr {
 
-// compute.comp:31-36 (the leaf type of the reference's first scene; its call site is commented out, ray.h:173-177)
-struct Sphere { float4 position; Material mat; float radius; float pad[3]; };
-
 // ray.h:66-78 with the reciprocal direction hoisted (it is a pure function of the ray).
 PTR_DEV bool hit_aabb(const float4 lo, const float4 hi, const f3 origin, const f3 inv_dir, float min_t, float max_t) {
     const f3 fv = (mk3(hi.x, hi.y, hi.z) - origin) * inv_dir;

@@ -16,6 +16,11 @@ struct Material {  // 48 bytes, include/material.hpp:17-25 / compute.comp:21-29
     float pad[2];
 };
 
+// compute.comp:31-36 (the leaf type of the reference's first scene; its call site is commented out, ray.h:173-177), 80 bytes
+struct Sphere { float4 position; Material mat; float radius; float pad[3]; };
+// a hit's primitive id with this bit set names sphere (id & ~tag) of SceneView::spheres; triangle ids stay below 2^29
+constexpr int32_t kSpherePrimTag = 0x40000000;
+
 struct ThreadedNode {  // 32 bytes, include/bvh.hpp:17-22 / compute.comp:60-65
     float min[3]; int32_t next_id;
     float max[3]; int32_t primitive_id;
@@ -70,6 +75,8 @@ struct SceneView {
     uint32_t instance_count;
     uint32_t object_triangles;       // two-level scenes: captured primitive ids read instance * object_triangles + primitive
     uint32_t batch_samples;          // wavefront pipeline: samples meta.sample_index, +1, ... traced by ONE dispatch (>= 1)
+    const Sphere* spheres;           // optional: the records the flattened layout's sphere leaves name
+    uint32_t sphere_count;
 };
 
 struct Ray { f3 origin, dir; float min_t, max_t; };
@@ -343,16 +350,30 @@ PTR_DEV bool shade_bounce(const SceneView& sv, uint32_t bounce, uint32_t min_bou
     const f3 v = -r.dir;
     const f3 bary = mk3(1.0f - hit.u - hit.v, hit.u, hit.v);
     ShadeInputs in;
-    if (sv.shade_records) {
+    const f3 point = r.origin + r.dir * hit.t;   // ray.h:191
+    const bool on_sphere = (hit.prim & kSpherePrimTag) != 0;
+    Material sphere_material;
+    if (on_sphere) {
+        // a sphere leaf: the frame hit_sphere's commented lines describe (ray.h:127-132) -- the outward normal
+        // (point - centre) / radius, here at all three "vertices" -- texture coordinates (0, 0), the record's own material
+        const uint32_t index = (uint32_t)(hit.prim & ~kSpherePrimTag);
+        if (!sv.spheres || index >= sv.sphere_count) return false;
+        const Sphere s = sv.spheres[index];
+        const f3 out = point - mk3(s.position.x, s.position.y, s.position.z);
+        in.geometry_normal = mk3(out.x / s.radius, out.y / s.radius, out.z / s.radius);
+        in.n0 = in.n1 = in.n2 = in.geometry_normal;
+        in.uv0.x = in.uv0.y = in.uv1.x = in.uv1.y = in.uv2.x = in.uv2.y = 0.0f;
+        in.material = 0u;
+        sphere_material = s.mat;
+    } else if (sv.shade_records) {
         if ((uint32_t)hit.prim >= sv.shade_record_count) return false;  // a hit that names no triangle of the index buffer
         in = load_shade_record(sv.shade_records + (size_t)hit.prim * kShadeRecordVec4);
     } else {
         in = gather_shade_inputs(sv, (uint32_t)hit.prim);
     }
 
-    // geometry normal and hit point as hit_triangle / hit_node produce them (ray.h:146,159,191)
+    // geometry normal as hit_triangle produces it (ray.h:146,159)
     f3 geometry_normal = in.geometry_normal;
-    const f3 point = r.origin + r.dir * hit.t;
 
     f3 shading_normal = normalize(((in.n0 * bary.x) + (in.n1 * bary.y)) + (in.n2 * bary.z));
     if (sv.instance_records && hit.inst >= 0) {
@@ -365,7 +386,7 @@ PTR_DEV bool shade_bounce(const SceneView& sv, uint32_t bounce, uint32_t min_bou
     const float tu = (in.uv0.x * bary.x + in.uv1.x * bary.y) + in.uv2.x * bary.z;
     const float tv = (in.uv0.y * bary.x + in.uv1.y * bary.y) + in.uv2.y * bary.z;
 
-    const Material mat = sv.materials[in.material];
+    const Material mat = on_sphere ? sphere_material : sv.materials[in.material];
     const f4 albedo = sample_bindless(sv, mat.albedo_tex, tu, tv);
     const f3 diffuse_color = srgb_to_linear(mk3(albedo.x, albedo.y, albedo.z)) * mk3(mat.base_color[0], mat.base_color[1], mat.base_color[2]);
     const f4 mr = sample_bindless(sv, mat.mr_tex, tu, tv);

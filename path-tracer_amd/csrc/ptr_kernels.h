@@ -104,8 +104,9 @@ hipError_t apply_reference_ranks(hipStream_t s, const ThreadedNode* nodes, uint3
 // Contents check of the buffers a "compute" dispatch dereferences (ptr_kernels_validate.hip).  out4 (device, 4 words):
 // max vertex id, max material id, violations in the threaded nodes, violations in the flattened layout (and in the top
 // level over its copies, fv->top, when there is one).
+// sphere_count: records the layout's sphere leaves may name (0: a sphere leaf is a violation).
 hipError_t launch_validate_scene(hipStream_t s, const SceneView& sv, uint32_t triangle_count, uint32_t threaded_nodes, const FlatView* fv,
-                                 uint32_t flat_nodes, uint32_t flat_triangles, uint32_t top_nodes, uint32_t* out4);
+                                 uint32_t flat_nodes, uint32_t flat_triangles, uint32_t top_nodes, uint32_t sphere_count, uint32_t* out4);
 
 // Stack entries a depth-first walk of the 4-wide tree at `nodes` can have pending at once (the figure a layout header
 // claims as max_depth), measured level by level.  Synchronous.  *status: 0 ok, -1 bad root, -2 more than `limit`

@@ -43,7 +43,8 @@ __global__ __launch_bounds__(256) void validate_threaded(const ThreadedNode* nod
 }
 
 // Flattened layout: child references inside the node / triangle arrays, primitive ids inside the index buffer.  out[3] = violations.
-__global__ __launch_bounds__(256) void validate_flat(FlatView fv, uint32_t node_count, uint32_t flat_triangles, uint32_t triangle_count, uint32_t* out) {
+__global__ __launch_bounds__(256) void validate_flat(FlatView fv, uint32_t node_count, uint32_t flat_triangles, uint32_t triangle_count, uint32_t sphere_count,
+                                                    uint32_t* out) {
     uint32_t bad = 0u;
     const uint32_t stride = gridDim.x * 256u;
     for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < node_count; i += stride) {
@@ -60,7 +61,12 @@ __global__ __launch_bounds__(256) void validate_flat(FlatView fv, uint32_t node_
     }
     for (uint32_t t = blockIdx.x * 256u + threadIdx.x; t < flat_triangles; t += stride) {
         const int32_t prim = __float_as_int(fv.triangles[4 * (size_t)t + 1].w);
-        if (prim < 0 || (uint32_t)prim >= triangle_count) bad++;
+        const int32_t kind = __float_as_int(fv.triangles[4 * (size_t)t + 2].w);
+        if (kind == 1) {   // a sphere record names one of the bound spheres
+            if (prim < 0 || (prim & kSpherePrimTag) == 0 || (uint32_t)(prim & ~kSpherePrimTag) >= sphere_count) bad++;
+        } else if (kind != 0 || prim < 0 || (uint32_t)prim >= triangle_count) {
+            bad++;
+        }
     }
     if (bad) atomicAdd(&out[3], bad);
 }
@@ -172,13 +178,13 @@ hipError_t measure_stack_need(hipStream_t s, const float4* nodes, uint32_t node_
 }
 
 hipError_t launch_validate_scene(hipStream_t s, const SceneView& sv, uint32_t triangle_count, uint32_t threaded_nodes, const FlatView* fv,
-                                 uint32_t flat_nodes, uint32_t flat_triangles, uint32_t top_nodes, uint32_t* out4) {
+                                 uint32_t flat_nodes, uint32_t flat_triangles, uint32_t top_nodes, uint32_t sphere_count, uint32_t* out4) {
     hipError_t e = hipMemsetAsync(out4, 0, 16, s);
     if (e != hipSuccess) return e;
     auto grid = [](uint32_t n) { const uint32_t b = (n + 255u) / 256u; return dim3(b < 1u ? 1u : (b > 4096u ? 4096u : b)); };
     if (triangle_count) hipLaunchKernelGGL(validate_indices, grid(triangle_count), dim3(256), 0, s, sv, triangle_count, out4);
     if (threaded_nodes) hipLaunchKernelGGL(validate_threaded, grid(threaded_nodes), dim3(256), 0, s, sv.nodes, threaded_nodes, triangle_count, out4);
-    if (fv) hipLaunchKernelGGL(validate_flat, grid(flat_nodes > flat_triangles ? flat_nodes : flat_triangles), dim3(256), 0, s, *fv, flat_nodes, flat_triangles, triangle_count, out4);
+    if (fv) hipLaunchKernelGGL(validate_flat, grid(flat_nodes > flat_triangles ? flat_nodes : flat_triangles), dim3(256), 0, s, *fv, flat_nodes, flat_triangles, triangle_count, sphere_count, out4);
     if (fv && fv->top.nodes)
         hipLaunchKernelGGL(validate_top, grid(top_nodes > fv->top.count ? top_nodes : fv->top.count), dim3(256), 0, s, fv->top, top_nodes, flat_nodes, flat_triangles, out4);
     return hipGetLastError();

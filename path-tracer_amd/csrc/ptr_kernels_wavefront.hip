@@ -12,6 +12,7 @@
 #pragma clang fp contract(off)
 
 #include "ptr_kernels.h"
+#include "ptr_device_intersect.h"
 
 namespace ptr {
 
@@ -132,6 +133,22 @@ PTR_DEV int32_t lane_value(int32_t v, int lane_index) { return __builtin_amdgcn_
 PTR_DEV uint32_t lane_value(uint32_t v, int lane_index) { return (uint32_t)__builtin_amdgcn_readlane((int)v, lane_index); }
 PTR_DEV float uniform_value(float v) { return __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(v))); }
 PTR_DEV int32_t uniform_value(int32_t v) { return __builtin_amdgcn_readfirstlane(v); }
+
+// A record of the layout's 64-byte primitive array that holds a sphere instead of a triangle (third float4's w = 1): centre in
+// the first float4, radius in the second one's x.  The test is the reference's hit_sphere (ray.h:105-135) against the ray
+// shortened to the best hit so far, which is how its commented call site in hit_node would run it (ray.h:173-177); a NaN
+// distance is no hit, and the barycentrics a triangle hit carries are zero.
+constexpr int32_t kRecordSphere = 1;
+PTR_DEV void sphere_leaf(float4 a, float4 b, f3 o, f3 d, float min_t, float best_t, float& t, float& u, float& v, bool& reject) {
+    Sphere s;
+    s.position = make_float4(a.x, a.y, a.z, 0.0f);
+    s.radius = b.x;
+    Ray r; r.origin = o; r.dir = d; r.min_t = min_t; r.max_t = best_t;
+    float ts = 0.0f;
+    const bool hit = hit_sphere(s, r, ts);
+    t = ts; u = 0.0f; v = 0.0f;
+    reject = !hit || ts != ts;
+}
 
 constexpr int32_t kTraversalDone = INT32_MIN;  // never a leaf reference: triangle counts stay below 2^29
 
@@ -338,10 +355,11 @@ __global__ __launch_bounds__(kExtendThreads, TWO_LEVEL ? 6 : 4) void ptr_wf_exte
                 const f3 ov = o - mk3(a.x, a.y, a.z);
                 const f3 q = cross(ov, d);
                 const float dd = rcp(dot(d, n));
-                const float u = dd * dot(-q, e2);
-                const float v = dd * dot(q, e1);
-                const float t = dd * dot(-n, ov);
-                const bool reject = u < 0.0f || u > 1.0f || v < 0.0f || u + v > 1.0f || t < min_t || t > best_t || t != t || u != u || v != v;
+                float u = dd * dot(-q, e2);
+                float v = dd * dot(q, e1);
+                float t = dd * dot(-n, ov);
+                bool reject = u < 0.0f || u > 1.0f || v < 0.0f || u + v > 1.0f || t < min_t || t > best_t || t != t || u != u || v != v;
+                if (!TWO_LEVEL && __float_as_int(c.w) == kRecordSphere) sphere_leaf(a, b, o, d, min_t, best_t, t, u, v, reject);
                 const int32_t rank = __float_as_int(a.w);
                 // equal t: the later (copy, rank) pair wins
                 const bool earlier = TWO_LEVEL ? (cur_inst < best_inst || (cur_inst == best_inst && rank < best_rank)) : rank < best_rank;
@@ -529,10 +547,11 @@ __global__ __launch_bounds__(kExtendThreads, TWO_LEVEL ? 6 : 4) void ptr_wf_exte
                     const f3 ov = ro - mk3(a.x, a.y, a.z);
                     const f3 q = cross(ov, rd);
                     const float dd = rcp(dot(rd, n));
-                    const float u = dd * dot(-q, e2);
-                    const float v = dd * dot(q, e1);
-                    const float t = dd * dot(-n, ov);
-                    const bool reject = u < 0.0f || u > 1.0f || v < 0.0f || u + v > 1.0f || t < min_t || t > bt || t != t || u != u || v != v;
+                    float u = dd * dot(-q, e2);
+                    float v = dd * dot(q, e1);
+                    float t = dd * dot(-n, ov);
+                    bool reject = u < 0.0f || u > 1.0f || v < 0.0f || u + v > 1.0f || t < min_t || t > bt || t != t || u != u || v != v;
+                    if (!TWO_LEVEL && __float_as_int(c.w) == kRecordSphere) sphere_leaf(a, b, ro, rd, min_t, bt, t, u, v, reject);
                     const int32_t rank = __float_as_int(a.w);
                     if (!reject && (t < ct || (t == ct && rank > crank))) { ct = t; cu = u; cv = v; crank = rank; cprim = __float_as_int(b.w); ccopy = copy; }
                     if (remaining == 0u) break;

@@ -391,7 +391,29 @@ void fill_flat_triangle(flat_bvh_triangle& out, const triangle& t, int32_t prim,
     out.n[2] = e1[0] * e2[1] - e2[0] * e1[1];
     out.rank = rank;
     out.primitive_id = prim;
-    out.pad0 = out.pad1 = 0;
+    out.kind = FLAT_BVH_KIND_TRIANGLE;
+    out.pad1 = 0;
+}
+
+void fill_flat_sphere(flat_bvh_triangle& out, const flat_bvh_sphere& s, int32_t index, int32_t rank) {
+    std::memset(&out, 0, sizeof out);
+    for (int i = 0; i < 3; i++) out.p0[i] = s.center[i];
+    out.e1[0] = s.radius;
+    out.rank = rank;
+    out.primitive_id = FLAT_BVH_SPHERE_TAG | index;
+    out.kind = FLAT_BVH_KIND_SPHERE;
+}
+
+// A sphere as the builder sees it: a "triangle" whose three points span the sphere's box (rounded outwards) and whose
+// centre is the sphere's.
+triangle sphere_proxy(const flat_bvh_sphere& s) {
+    const float inf = std::numeric_limits<float>::infinity();
+    float lo[3], hi[3];
+    for (int i = 0; i < 3; i++) {
+        lo[i] = std::nextafter(s.center[i] - s.radius, -inf);
+        hi[i] = std::nextafter(s.center[i] + s.radius, inf);
+    }
+    return triangle(vec3(lo[0], lo[1], lo[2]), vec3(hi[0], hi[1], hi[2]), vec3(s.center[0], s.center[1], s.center[2]));
 }
 
 }  // namespace
@@ -596,10 +618,22 @@ void write_wide_nodes(const std::vector<sah_node>& nodes, const wide_layout& L, 
 
 }  // namespace
 
-std::vector<uint8_t> bvh::flatten(const std::vector<triangle>& tris, const std::vector<int32_t>& ranks, unsigned threads) {
-    if (tris.empty()) throw bvh_build_error("flatten: no triangles");
-    if (tris.size() >= (1u << 29)) throw bvh_build_error("flatten: too many triangles for the leaf reference encoding");
-    if (!ranks.empty() && ranks.size() != tris.size()) throw bvh_build_error("flatten: ranks/triangles size mismatch");
+std::vector<uint8_t> bvh::flatten(const std::vector<triangle>& only_tris, const std::vector<int32_t>& ranks, unsigned threads,
+                                  const std::vector<flat_bvh_sphere>& spheres) {
+    if (only_tris.empty() && spheres.empty()) throw bvh_build_error("flatten: no triangles");
+    if (only_tris.size() + spheres.size() >= (1u << 29)) throw bvh_build_error("flatten: too many triangles for the leaf reference encoding");
+    if (!ranks.empty() && ranks.size() != only_tris.size()) throw bvh_build_error("flatten: ranks/triangles size mismatch");
+    for (const flat_bvh_sphere& s : spheres)
+        if (!(s.radius > 0.0f) || !std::isfinite(s.radius) || !std::isfinite(s.center[0]) || !std::isfinite(s.center[1]) || !std::isfinite(s.center[2]))
+            throw bvh_build_error("flatten: a sphere needs a finite centre and a positive finite radius");
+    // the tree is built over the triangles and, behind them, one box-spanning proxy per sphere
+    std::vector<triangle> with_proxies;
+    if (!spheres.empty()) {
+        with_proxies = only_tris;
+        for (const flat_bvh_sphere& s : spheres) with_proxies.push_back(sphere_proxy(s));
+    }
+    const std::vector<triangle>& tris = spheres.empty() ? only_tris : with_proxies;
+    const size_t triangle_count = only_tris.size();
 
     std::vector<int32_t> order;
     const std::vector<sah_node> nodes = build_sah(tris, order, 4, threads);
@@ -625,7 +659,8 @@ std::vector<uint8_t> bvh::flatten(const std::vector<triangle>& tris, const std::
         // leaves of collapsed-away inner nodes are still reached through their wide ancestor
         for (uint32_t k = 0; k < nd.count; k++) {
             const int32_t prim = order[nd.first + k];
-            fill_flat_triangle(out_tris[L.leaf_first[id] + k], tris[prim], prim, ranks.empty() ? prim : ranks[prim]);
+            if ((size_t)prim < triangle_count) fill_flat_triangle(out_tris[L.leaf_first[id] + k], tris[prim], prim, ranks.empty() ? prim : ranks[prim]);
+            else fill_flat_sphere(out_tris[L.leaf_first[id] + k], spheres[(size_t)prim - triangle_count], (int32_t)((size_t)prim - triangle_count), prim);
         }
     }
     write_wide_nodes(nodes, L, out_nodes, reference_to);

@@ -49,12 +49,19 @@ static_assert(sizeof(flat_bvh_node) == 64, "flat node is one 64-byte line");
 // computed here in fp32 with the shader's operation order so the kernel's u, v, t keep their bits.
 // `rank` is the triangle's position in the reference traversal order (tie-break on equal t:
 // the reference keeps the later-visited triangle, ray.h:153).
+//
+// A record can also hold a sphere -- the primitive of the reference's hit_sphere (shaders/include/ray.h:105-135), whose call
+// site in hit_node is commented out (ray.h:173-177): kind = FLAT_BVH_KIND_SPHERE, p0 = centre, e1[0] = radius, primitive_id =
+// FLAT_BVH_SPHERE_TAG | index into the sphere array bound beside the layout; e2 and n are unused.
 struct flat_bvh_triangle {
     float p0[3]; int32_t rank;
     float e1[3]; int32_t primitive_id;
-    float e2[3]; int32_t pad0;
+    float e2[3]; int32_t kind;
     float n[3];  int32_t pad1;
 };
+constexpr int32_t FLAT_BVH_KIND_TRIANGLE = 0, FLAT_BVH_KIND_SPHERE = 1;
+constexpr int32_t FLAT_BVH_SPHERE_TAG = 0x40000000;   // triangle ids stay below 2^29
+struct flat_bvh_sphere { float center[3]; float radius; };
 static_assert(sizeof(flat_bvh_triangle) == 64, "flat triangle is one 64-byte line");
 
 struct flat_bvh_header {
@@ -122,8 +129,10 @@ public:
 
     // GPU layout.  `ranks` (one per primitive) may be empty: then rank = primitive index.
     // Returns one contiguous blob: header | nodes | triangles.
+    // `spheres`: further primitives of the same tree (sphere leaves); sphere s hits report primitive FLAT_BVH_SPHERE_TAG | s
+    // and rank triangles.size() + s.
     static std::vector<uint8_t> flatten(const std::vector<triangle>& triangles, const std::vector<int32_t>& ranks,
-                                        unsigned threads = 0);
+                                        unsigned threads = 0, const std::vector<flat_bvh_sphere>& spheres = {});
 
     // Several objects in ONE layout: triangles [object_first[k], object_first[k + 1]) form object k, each with a tree of
     // its own; node and triangle records of all objects share the blob's two arrays and primitive ids stay global, so the

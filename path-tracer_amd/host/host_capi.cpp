@@ -85,6 +85,28 @@ int32_t ptrh_bvh_flatten(const float* positions, int64_t n, const int32_t* ranks
     }
 }
 
+int32_t ptrh_bvh_flatten_spheres(const float* positions, int64_t n, const int32_t* ranks, const float* spheres, int64_t sphere_count, uint32_t threads,
+                                 void** blob_out, uint64_t* size_out) {
+    try {
+        if (n < 0 || sphere_count < 0 || n + sphere_count <= 0 || (sphere_count && !spheres)) { g_last_error = "ptrh_bvh_flatten_spheres: no primitives"; return -1; }
+        const std::vector<triangle> tris = n ? make_triangles(positions, n) : std::vector<triangle>();
+        std::vector<int32_t> r;
+        if (ranks) r.assign(ranks, ranks + n);
+        std::vector<flat_bvh_sphere> s((size_t)sphere_count);
+        if (sphere_count) std::memcpy(s.data(), spheres, (size_t)sphere_count * sizeof(flat_bvh_sphere));
+        const std::vector<uint8_t> blob = bvh::flatten(tris, r, threads, s);
+        void* mem = std::malloc(blob.size());
+        if (!mem) { g_last_error = "ptrh_bvh_flatten_spheres: out of memory"; return -1; }
+        std::memcpy(mem, blob.data(), blob.size());
+        *blob_out = mem;
+        *size_out = blob.size();
+        return 0;
+    } catch (const std::exception& e) {
+        g_last_error = e.what();
+        return -1;
+    }
+}
+
 int32_t ptrh_bvh_flatten_instances(const void* object_blob, uint64_t object_bytes, const float* object_to_world, int64_t instance_count,
                                    uint32_t threads, void** blob_out, uint64_t* size_out) {
     try {

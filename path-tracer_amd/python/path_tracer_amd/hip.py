@@ -14,7 +14,7 @@ import os
 
 import numpy as np
 
-from . import paths
+from . import paths, scenes
 
 FORMAT_RGBA8_UNORM = 37
 FORMAT_RGBA32_SFLOAT = 109
@@ -62,6 +62,7 @@ def lib():
         "ptr_image_address": [vp, u32, P(u64)],
         "ptr_bvh_bind_flat": [vp, u32, u32],
         "ptr_bvh_bind_instances": [vp, u32, u32],
+        "ptr_bvh_bind_spheres": [vp, u32, u32, u32],
         "ptr_dispatch": [vp, C.c_char_p, vp, u32, u32, u32],
         "ptr_dispatch_static": [vp, C.c_char_p, vp, u32, u32, u32],
         "ptr_set_partition": [vp, u32, u32, u32],
@@ -92,7 +93,7 @@ def lib():
 ABI_SYMBOLS = ["ptr_ctx_create", "ptr_ctx_destroy", "ptr_ctx_set_stream", "ptr_last_error", "ptr_sync", "ptr_flush", "ptr_buffer_create",
                "ptr_buffer_destroy", "ptr_buffer_write", "ptr_buffer_read", "ptr_buffer_address", "ptr_sampler_create",
                "ptr_image_create", "ptr_image_wrap", "ptr_image_destroy", "ptr_image_upload", "ptr_image_read", "ptr_image_read_unorm8",
-               "ptr_image_index", "ptr_sampler_index", "ptr_image_address", "ptr_bvh_bind_flat", "ptr_bvh_bind_instances", "ptr_dispatch", "ptr_dispatch_static",
+               "ptr_image_index", "ptr_sampler_index", "ptr_image_address", "ptr_bvh_bind_flat", "ptr_bvh_bind_instances", "ptr_bvh_bind_spheres", "ptr_dispatch", "ptr_dispatch_static",
                "ptr_set_partition", "ptr_image_pack_stripes", "ptr_image_unpack_stripes", "ptr_set_sample_partition", "ptr_set_option", "ptr_set_capture", "ptr_stats_enable", "ptr_stats_read", "ptr_profile_enable",
                "ptr_profile_read", "ptr_profile_names", "ptr_device_function", "ptr_bvh_build_flat", "ptr_bvh_flat_set_reference_ranks"]
 
@@ -217,6 +218,11 @@ class Context:
     def bind_instances(self, flat_buffer, instance_buffer):
         """Top level over placed copies of the layout in flat_buffer (host.bvh_flatten_instances); None removes it."""
         self._check(self._L.ptr_bvh_bind_instances(self.handle, flat_buffer.handle, instance_buffer.handle if instance_buffer is not None else 0))
+
+    def bind_spheres(self, flat_buffer, sphere_buffer, count=0):
+        """The 80-byte sphere records (compute.comp:31-36) named by the sphere leaves of the layout in flat_buffer
+        (host.bvh_flatten(..., spheres=...)); None removes them."""
+        self._check(self._L.ptr_bvh_bind_spheres(self.handle, flat_buffer.handle, sphere_buffer.handle if sphere_buffer is not None else 0, count))
 
     def dispatch(self, kernel, constants, gx, gy, gz=1):
         k = np.ascontiguousarray(constants, dtype=np.uint8)
@@ -399,6 +405,17 @@ class GpuScene:
         if flat is not None and arrays.get("flat_instances") is not None:
             self.instance_buffer = upload(arrays["flat_instances"])
             ctx.bind_instances(self.flat_buffer, self.instance_buffer)
+        self.sphere_buffer = None
+        if flat is not None and arrays.get("sphere_records") is not None:
+            records = np.array(arrays["sphere_records"], dtype=scenes.SPHERE_DTYPE, copy=True)
+            m = records["material"]   # the embedded materials name textures the same way the material buffer does
+            m["albedo_tex"] = [tex_index[int(x)] for x in m["albedo_tex"]]
+            m["mr_tex"] = [tex_index[int(x)] for x in m["mr_tex"]]
+            m["albedo_sampler"] = np.where(m["albedo_tex"] > 0, self.sampler.bindless_index, 0)
+            m["mr_sampler"] = np.where(m["mr_tex"] > 0, self.sampler.bindless_index, 0)
+            self.spheres_host = records
+            self.sphere_buffer = upload(records)
+            ctx.bind_spheres(self.flat_buffer, self.sphere_buffer, len(records))
         self.meta = None
         if meta is not None:
             self.set_meta(meta)

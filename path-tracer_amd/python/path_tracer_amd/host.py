@@ -19,6 +19,9 @@ def lib():
         L.ptrh_bvh_visit_ranks.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]
         L.ptrh_bvh_flatten.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p),
                                        C.POINTER(C.c_uint64)]
+        L.ptrh_bvh_flatten_spheres.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_uint32, C.POINTER(C.c_void_p),
+                                               C.POINTER(C.c_uint64)]
+        L.ptrh_bvh_flatten_spheres.restype = C.c_int32
         L.ptrh_bvh_flatten_instances.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_int64, C.c_uint32, C.POINTER(C.c_void_p),
                                                  C.POINTER(C.c_uint64)]
         L.ptrh_bvh_flatten_instances.restype = C.c_int32
@@ -74,14 +77,20 @@ def bvh_visit_ranks(nodes, primitive_count):
     return ranks
 
 
-def bvh_flatten(triangles, ranks=None, threads=0):
-    """Returns the GPU layout blob (uint8 array): 64-byte header | 64-byte nodes | 64-byte triangles."""
+def bvh_flatten(triangles, ranks=None, threads=0, spheres=None):
+    """Returns the GPU layout blob (uint8 array): 64-byte header | 64-byte nodes | 64-byte triangles.
+    spheres: optional (S, 4) array of centre + radius, the sphere leaves of the same tree."""
     tri = np.ascontiguousarray(triangles, dtype=np.float32).reshape(-1, 9)
     n = tri.shape[0]
     r = None if ranks is None else np.ascontiguousarray(ranks, dtype=np.int32)
     ptr = C.c_void_p()
     size = C.c_uint64()
-    rc = lib().ptrh_bvh_flatten(tri.ctypes.data, n, None if r is None else r.ctypes.data, threads, C.byref(ptr), C.byref(size))
+    if spheres is not None and len(spheres):
+        sp = np.ascontiguousarray(spheres, dtype=np.float32).reshape(-1, 4)
+        rc = lib().ptrh_bvh_flatten_spheres(tri.ctypes.data if n else None, n, None if r is None else r.ctypes.data, sp.ctypes.data, sp.shape[0], threads,
+                                            C.byref(ptr), C.byref(size))
+    else:
+        rc = lib().ptrh_bvh_flatten(tri.ctypes.data, n, None if r is None else r.ctypes.data, threads, C.byref(ptr), C.byref(size))
     if rc != 0:
         raise HostError(lib().ptrh_last_error().decode())
     try:

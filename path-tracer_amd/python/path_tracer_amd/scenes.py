@@ -15,6 +15,9 @@ MATERIAL_DTYPE = np.dtype([("base_color", "<f4", 4), ("albedo_tex", "<u4"), ("al
                            ("mr_tex", "<u4"), ("mr_sampler", "<u4"), ("metalness", "<f4"), ("roughness", "<f4"),
                            ("pad", "<f4", 2)])
 assert MATERIAL_DTYPE.itemsize == 48
+# the shader's `sphere` struct (compute.comp:31-36): vec4 position, material, float radius, padded to a multiple of 16 bytes
+SPHERE_DTYPE = np.dtype([("position", "<f4", 4), ("material", MATERIAL_DTYPE), ("radius", "<f4"), ("pad", "<f4", 3)])
+assert SPHERE_DTYPE.itemsize == 80
 
 MAX_PRIMITIVE_VERTICES = 65535  # the reference's loader reads u16 indices only (include/mesh.hpp:87)
 

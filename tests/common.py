@@ -19,7 +19,20 @@ def make_bundle(kind="tiny", target=4000, width=64, height=40, seed=None, **meta
     return dict(sc, nodes=nodes, ranks=ranks, flat=flat, meta=meta, width=width, height=height)
 
 
-def oracle_frames(bundle, spp, use_flat=False, materials=None, textures=None, aov=False, threads=None, first_sample=1):
+def add_spheres(bundle, spheres):
+    """The bundle with sphere leaves: `spheres` is a list of (centre, radius, material record); the flattened layout is rebuilt
+    over the triangles and the spheres, the 80-byte records go to bundle["sphere_records"]."""
+    records = np.zeros(len(spheres), dtype=scenes.SPHERE_DTYPE)
+    for i, (centre, radius, material) in enumerate(spheres):
+        records[i]["position"] = list(centre) + [0.0]
+        records[i]["material"] = material
+        records[i]["radius"] = radius
+    geometry = np.concatenate([records["position"][:, :3], records["radius"][:, None]], axis=1).astype(np.float32)
+    flat = host.bvh_flatten(bundle["triangles"], bundle["ranks"], spheres=geometry)
+    return dict(bundle, flat=flat, sphere_records=records)
+
+
+def oracle_frames(bundle, spp, use_flat=False, materials=None, textures=None, aov=False, threads=None, first_sample=1, spheres=None):
     """Renders sample_index = first_sample .. first_sample+spp-1 with the CPU oracle, ping-ponging the two images
     like src/main.cpp:406-416.  Returns (image, counters of the last frame, (aov_prim, aov_t) of the last frame)."""
     import pyoracle
@@ -28,6 +41,8 @@ def oracle_frames(bundle, spp, use_flat=False, materials=None, textures=None, ao
         arrays["materials"] = materials
     if textures is not None:
         arrays["textures"] = textures
+    if spheres is not None:
+        arrays["sphere_records"] = spheres
     o = pyoracle.OracleScene(arrays)
     H, W = bundle["height"], bundle["width"]
     acc = np.zeros((H, W, 4), np.float32)
