@@ -210,7 +210,7 @@ def pmc_traffic(kernel, workload, samples_per_dispatch=None):
         samples_per_dispatch = pmc_traffic.samples_per_dispatch
     if rec is None or t.get("workload") != workload:
         return None, "profiles/traffic.json holds no counters for this kernel and workload", {}
-    extra = {k: rec[k] for k in ("valu_busy", "l2_hit_rate", "l1_hit_rate", "waves_waiting", "per_launch") if k in rec}
+    extra = {k: rec[k] for k in ("valu_one_pipe_share", "l2_hit_rate", "l1_hit_rate", "waves_waiting", "per_launch") if k in rec}
     recorded = t.get("samples_per_dispatch", 1)
     if recorded == samples_per_dispatch:
         return rec["bytes_per_launch"], t.get("note", ""), extra
@@ -696,18 +696,20 @@ def main():
         solo = ctx.profile_read(reset=True)
         # one sample rendered alone: one dispatch of one sample, nothing else in flight, host waits for it (the latency a caller
         # sees who needs every frame before it issues the next; not a throughput figure)
-        keep_spd = loop.samples_per_dispatch
-        loop.samples_per_dispatch = 1
-        loop.reset()
-        loop.frames(2); torch.cuda.synchronize()
-        lat = []
-        for _ in range(min(args.steps, 10)):
-            t_l = time.perf_counter()
-            loop.frames(1)
-            torch.cuda.synchronize()
-            lat.append(time.perf_counter() - t_l)
-        single_frame_latency_ms = sorted(lat)[len(lat) // 2] * 1e3
-        loop.samples_per_dispatch = keep_spd
+        single_frame_latency_ms = None
+        if not os.environ.get("PTR_BENCH_SKIP_SINGLE"):   # (skipped under counter passes, like the one-sample leg below)
+            keep_spd = loop.samples_per_dispatch
+            loop.samples_per_dispatch = 1
+            loop.reset()
+            loop.frames(2); torch.cuda.synchronize()
+            lat = []
+            for _ in range(min(args.steps, 10)):
+                t_l = time.perf_counter()
+                loop.frames(1)
+                torch.cuda.synchronize()
+                lat.append(time.perf_counter() - t_l)
+            single_frame_latency_ms = sorted(lat)[len(lat) // 2] * 1e3
+            loop.samples_per_dispatch = keep_spd
         ctx.set_option("frames.in_flight", args.frames_in_flight)
 
         # what a caller pays on top when it reads every finished frame back over PCIe (33 MB at 1080p)

@@ -10,12 +10,17 @@ rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 ms = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in rows]
 line = json.loads(open(sys.argv[2]).read().strip().splitlines()[-1])
 timed = line["roofline"]["launches"]
-# launch order of the run: warm-up, the timed region, [the one-sample leg, skipped under PTR_BENCH_SKIP_SINGLE], the solo leg
+# launch order of the run: warm-up, the timed region, the solo leg, then whatever else the run does (the one-sample legs unless
+# PTR_BENCH_SKIP_SINGLE is set, the parity check's one-sample frames unless --skip-parity is given)
+cfg = line["config"]
+per_dispatch = timed // max(1, cfg["dispatches_per_gpu"])
+warm = -(-cfg["warmup_steps_run"] // cfg["samples_per_dispatch"]) * per_dispatch
 solo = timed
-warm = len(ms) - timed - solo
 mean = lambda v: sum(v) / max(1, len(v))
 print(f"kernel ptr_wf_extend<false, ...>: {len(ms)} launches in the trace, all: {mean(ms):.4f} ms")
 print("per launch, ms:", " ".join(f"{x:.3f}" for x in ms))
 print(f"warm-up   ({warm:3d} launches): {mean(ms[:warm]):.4f} ms")
 print(f"timed     ({timed:3d} launches): {mean(ms[warm:warm + timed]):.4f} ms   bench line roofline.avg_launch_ms      = {line['roofline']['avg_launch_ms']:.4f}")
-print(f"solo      ({solo:3d} launches): {mean(ms[warm + timed:]):.4f} ms   bench line roofline.solo.avg_launch_ms = {line['roofline']['solo']['avg_launch_ms']:.4f}")
+print(f"solo      ({solo:3d} launches): {mean(ms[warm + timed:warm + timed + solo]):.4f} ms   bench line roofline.solo_avg_launch_ms = {line['roofline']['solo_avg_launch_ms']:.4f}")
+rest = ms[warm + timed + solo:]
+print(f"afterwards ({len(rest):3d} launches, one sample each): {mean(rest):.4f} ms")

@@ -52,8 +52,9 @@ def main():
         kernels[name] = dict(fetch_size_kib=fetch[name], write_size_kib=write.get(name, 0.0), launches_sampled=n[name],
                              bytes_per_launch=2.0 * fb + wb)
         if name in valu and busy.get(name):
-            # a wave64 VALU instruction occupies its SIMD for 4 cycles; 1024 SIMDs; GRBM_GUI_ACTIVE sums the 8 XCDs
-            kernels[name]["valu_busy"] = valu[name] * 4.0 / (1024.0 * busy[name] / 8.0)
+            # cycles ONE pipe would need for every vector instruction (4 per wave64 instruction) over the cycles the kernel ran
+            # (1024 SIMDs; GRBM_GUI_ACTIVE sums the 8 XCDs): above 1 means both pipes issued
+            kernels[name]["valu_one_pipe_share"] = valu[name] * 4.0 / (1024.0 * busy[name] / 8.0)
         if name in hit and hit[name] + miss.get(name, 0.0) > 0:
             kernels[name]["l2_hit_rate"] = hit[name] / (hit[name] + miss[name])
         if name in l1_req and l1_req[name] > 0:

@@ -110,7 +110,7 @@ def test_traffic_is_reported_only_for_the_workload_it_was_measured_on():
     recorded = t.get("samples_per_dispatch", 1)
     per_launch = t["kernels"]["wavefront.extend"]["bytes_per_launch"]
     got, _, counters = bench.pmc_traffic("wavefront.extend", t["workload"], recorded)
-    assert got == per_launch and "valu_busy" in counters
+    assert got == per_launch and "valu_one_pipe_share" in counters
     # launches of another size: scaled by the samples per launch, and the note says so
     got, note, _ = bench.pmc_traffic("wavefront.extend", t["workload"], recorded + 3)
     assert got == per_launch * (recorded + 3) / recorded and note.startswith("scaled from")
