@@ -436,6 +436,14 @@ def launch_ranks(n):
     process's; the other ranks' goes to standard error.  Returns the exit status: non-zero as soon as any rank fails."""
     import socket
     import subprocess
+    for var in ("ROCP_TOOL_LIBRARIES", "ROCPROFILER_REGISTER_FORCE_LOAD", "HSA_TOOLS_LIB"):
+        if os.environ.get(var):
+            # a profiler's preloaded library has initialised the GPU in this process already: starting the ranks from it is
+            # exactly what must not happen.  Profile one rank instead (the launcher's environment set by hand).
+            print(f"[bench] --gpus {n} under a profiler ({var} is set): this process would start the ranks after the GPU was initialised. "
+                  f"Profile one rank: RANK=r LOCAL_RANK=r WORLD_SIZE={n} MASTER_ADDR=127.0.0.1 MASTER_PORT=p <profiler> -- python3 bench.py --gpus {n} ...",
+                  file=sys.stderr)
+            return 2
     import torch
     if not os.environ.get("PTR_BENCH_DRY_RUN") and "PTR_BENCH_DEVICE" not in os.environ:
         found = torch.cuda.device_count()

@@ -95,6 +95,16 @@ def test_a_rank_that_fails_fails_the_launcher():
     assert out.returncode != 0 and out.stdout.strip() == ""
 
 
+def test_the_launcher_does_not_start_ranks_under_a_profiler():
+    """A profiler's preloaded library initialises the GPU before main(): starting other programs from such a process is what the
+    launcher exists to avoid, so it says how to profile one rank and stops."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(PTR_BENCH_DRY_RUN="1", PTR_BENCH_BACKEND="gloo", HSA_TOOLS_LIB="/nonexistent/librocprofiler-sdk-tool.so")
+    out = subprocess.run([sys.executable, os.path.join(bench.ROOT, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 2 and out.stdout.strip() == "" and "Profile one rank" in out.stderr
+
+
 def test_multi_gpu_lines_say_how_the_work_was_shared():
     args, sc, stats, prof, solo, rays = fake_inputs()
     tiles = bench.result_line(args, sc, 1920, 1080, 8, True, 0.004, 0.024, float(rays), stats, prof, solo, args.steps, {})
