@@ -35,6 +35,10 @@ int32_t ptrh_bvh_flatten(const float* positions, int64_t n, const int32_t* ranks
  * Sphere s reports primitive 0x40000000 | s; n may be 0. */
 int32_t ptrh_bvh_flatten_spheres(const float* positions, int64_t n, const int32_t* ranks, const float* spheres, int64_t sphere_count, uint32_t threads,
                                  void** blob_out, uint64_t* size_out);
+/* scene_source::random_spheres(): the scene of the reference's commented-out scene::random_scene (src/scene.cpp:11-58) -- a ground
+ * sphere, a 22 x 22 field of small ones, three large ones -- deterministic in `seed`.  Writes up to `capacity` records of 9 floats
+ * (x y z radius r g b metalness roughness) and the number of spheres the scene has (call with capacity 0 to ask). */
+int32_t ptrh_random_spheres(uint32_t seed, float* out9, uint32_t capacity, uint32_t* count_out);
 /* bvh::flatten_instances(): the top level over `instance_count` placed copies of one flattened tree -- an extension,
  * the reference has no instancing (its scene is one triangle soup, src/scene.cpp:84-176).  object_blob is
  * ptrh_bvh_flatten()'s (or ptr_bvh_build_flat()'s) output; object_to_world holds 12 floats per instance, the three

@@ -146,7 +146,9 @@ int launch_ranks(int argc, char** argv, uint32_t gpus, std::string rendezvous) {
 }  // namespace
 
 const char kUsage[] =
-    "usage: ptr_headless --scene file.{ptrscene,gltf,glb} [options]\n"
+    "usage: ptr_headless --scene file.{ptrscene,gltf,glb} | --spheres file.txt | --random-spheres SEED [options]\n"
+    "  spheres   --spheres FILE (one per line: x y z radius r g b metalness roughness)   --random-spheres SEED (the reference's old scene of spheres)\n"
+    "            alone or beside --scene: they become sphere leaves of the same tree\n"
     "  scene     --apply-transforms | --instanced (glTF node transforms: applied to the geometry | kept as placed copies)\n"
     "            --copies NX NZ (the scene placed on a grid through a top-level tree)   --gpu-bvh (tree built on the GPU)\n"
     "  frame     --width W --height H --spp N --max-bounce N --min-bounce N --downscale N --dof 0|1 --debug-bvh 0|1\n"
@@ -161,7 +163,8 @@ const char kUsage[] =
     "            (do not profile the --gpus N launcher: profile one rank, --rank R --gpus N --rendezvous DIR)\n";
 
 int main(int argc, char** argv) {
-    std::string scene_path, out_path, pipeline = "compute", checkpoint_path, resume_path;
+    std::string scene_path, spheres_path, out_path, pipeline = "compute", checkpoint_path, resume_path;
+    long random_spheres_seed = -1;
     uint32_t checkpoint_every = 0;
     bool apply_transforms = false, gpu_bvh = false, instanced = false;
     uint32_t copies_x = 1, copies_z = 1;
@@ -176,6 +179,8 @@ int main(int argc, char** argv) {
         auto is = [&](const char* name) { return std::strcmp(argv[i], name) == 0; };
         auto next = [&]() -> const char* { if (i + 1 >= argc) { std::fprintf(stderr, "%s needs a value\n", argv[i]); std::exit(2); } return argv[++i]; };
         if (is("--scene")) scene_path = next();
+        else if (is("--spheres")) spheres_path = next();
+        else if (is("--random-spheres")) random_spheres_seed = std::atol(next());
         else if (is("--apply-transforms")) apply_transforms = true;
         else if (is("--gpu-bvh")) gpu_bvh = true;
         else if (is("--instanced")) instanced = true;
@@ -210,7 +215,7 @@ int main(int argc, char** argv) {
         else if (is("--help") || is("-h")) { std::fputs(kUsage, stdout); return 0; }
         else { std::fprintf(stderr, "unknown argument %s\n%s", argv[i], kUsage); return 2; }
     }
-    if (scene_path.empty()) { std::fputs(kUsage, stderr); return 2; }
+    if (scene_path.empty() && spheres_path.empty() && random_spheres_seed < 0) { std::fputs(kUsage, stderr); return 2; }
 
     if (gpus == 0 || (partition != "tiles" && partition != "samples")) { std::fprintf(stderr, "--gpus N >= 1, --partition tiles|samples\n"); return 2; }
     // (Nothing above this line may call HIP -- no hiprenderer, no device query: launch_ranks() starts this program again.)
@@ -235,8 +240,14 @@ int main(int argc, char** argv) {
         uint32_t frames = (gpus > 1 && !tiles) ? spp / gpus : spp;
         const float aspect_ratio = (float)width / (float)height;
         const auto t_build = std::chrono::steady_clock::now();
+        scene_source source = scene_path.empty() ? scene_source() : load_source(scene_path, apply_transforms, instanced);
+        if (!spheres_path.empty()) source.spheres = scene_source::load_spheres(spheres_path);
+        if (random_spheres_seed >= 0) {
+            const auto more = scene_source::random_spheres((uint32_t)random_spheres_seed);
+            source.spheres.insert(source.spheres.end(), more.begin(), more.end());
+        }
         scene main_scene(camera(point3{ pos[0], pos[1], pos[2] }, point3{ target[0], target[1], target[2] }, v_fov, aspect_ratio, aperture, focus), width, height,
-                         load_source(scene_path, apply_transforms, instanced), pipeline != "compute.megakernel", gpu_bvh);
+                         source, pipeline != "compute.megakernel", gpu_bvh);
         main_scene.meta.max_bounce = max_bounce; main_scene.meta.min_bounce = min_bounce;
         main_scene.meta.enable_dof = dof; main_scene.meta.debug_bvh = debug_bvh; main_scene.meta.downscale_factor = downscale;
         if (copies_x * copies_z > 1) main_scene.place_copies_on_grid(copies_x, copies_z);  // the scene repeated on a grid, through a top-level tree

@@ -107,6 +107,24 @@ int32_t ptrh_bvh_flatten_spheres(const float* positions, int64_t n, const int32_
     }
 }
 
+int32_t ptrh_random_spheres(uint32_t seed, float* out9, uint32_t capacity, uint32_t* count_out) {
+    try {
+        if (!count_out || (capacity && !out9)) { g_last_error = "ptrh_random_spheres: null argument"; return -1; }
+        const std::vector<scene_source::source_sphere> all = scene_source::random_spheres(seed);
+        *count_out = (uint32_t)all.size();
+        for (uint32_t i = 0; i < capacity && i < all.size(); i++) {
+            const auto& s = all[i];
+            const float rec[9] = { s.center[0], s.center[1], s.center[2], s.radius, s.material.base_color[0], s.material.base_color[1], s.material.base_color[2],
+                                   s.material.metalness, s.material.roughness };
+            std::memcpy(out9 + 9 * (size_t)i, rec, sizeof rec);
+        }
+        return 0;
+    } catch (const std::exception& e) {
+        g_last_error = e.what();
+        return -1;
+    }
+}
+
 int32_t ptrh_bvh_flatten_instances(const void* object_blob, uint64_t object_bytes, const float* object_to_world, int64_t instance_count,
                                    uint32_t threads, void** blob_out, uint64_t* size_out) {
     try {

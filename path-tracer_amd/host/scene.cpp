@@ -6,13 +6,16 @@
 
 #include "bvh.hpp"
 #include "hip-renderer.hpp"
+#include "sphere.hpp"
 
 scene::metadata::metadata(const camera& cam_, uint32_t width_, uint32_t height_) : cam(cam_), width(width_), height(height_) {}
 
 scene::scene(const camera& cam, uint32_t width, uint32_t height, const scene_source& src, bool flatten_bvh, bool gpu_bvh) : meta(cam, width, height) {
     const uint32_t iw = src.index_words;
     if (iw != 3 && iw != 4) throw std::runtime_error("scene: index_words must be 3 or 4");
-    if (src.indices.empty() || src.indices.size() % iw) throw std::runtime_error("scene: the index array must hold whole triangles");
+    if ((src.indices.empty() && src.spheres.empty()) || src.indices.size() % iw) throw std::runtime_error("scene: the index array must hold whole triangles");
+    if (!src.spheres.empty() && !flatten_bvh) throw std::runtime_error("scene: spheres are leaves of the flattened layout; the threaded tree has no place for them");
+    if (!src.spheres.empty() && (!src.placements.empty() || gpu_bvh)) throw std::runtime_error("scene: spheres go with neither placed copies nor the GPU builder");
     const size_t vertex_count = src.positions.size() / 3;
     if (iw == 3 && vertex_count >= (1u << 24)) throw std::runtime_error("scene: more than 2^24 vertices do not fit the packed index words");
     if (iw == 3 && src.materials.size() >= (1u << 24)) throw std::runtime_error("scene: more than 2^24 materials");
@@ -30,7 +33,7 @@ scene::scene(const camera& cam, uint32_t width, uint32_t height, const scene_sou
 
     // one gpu_material per primitive with bindless indices (src/scene.cpp:145-163); 0 = no texture = white
     std::vector<gpu_material> materials;
-    for (const auto& m : src.materials) {
+    auto to_gpu = [&](const scene_source::source_material& m) {
         gpu_material g;
         g.base_color = color(m.base_color[0], m.base_color[1], m.base_color[2]);
         g.base_color.v[3] = m.base_color[3];
@@ -44,7 +47,18 @@ scene::scene(const camera& cam, uint32_t width, uint32_t height, const scene_sou
         bind(m.mr_texture, g.metallic_roughness_texture_id, g.metallic_roughness_texture_sampler_id);
         g.metalness = m.metalness;
         g.roughness = m.roughness;
-        materials.push_back(g);
+        return g;
+    };
+    for (const auto& m : src.materials) materials.push_back(to_gpu(m));
+    std::vector<gpu_sphere> sphere_records;
+    std::vector<flat_bvh_sphere> sphere_geometry;
+    for (const auto& s : src.spheres) {
+        gpu_sphere g;
+        g.position[0] = s.center[0]; g.position[1] = s.center[1]; g.position[2] = s.center[2];
+        g.mat = to_gpu(s.material);
+        g.radius = s.radius;
+        sphere_records.push_back(g);
+        sphere_geometry.push_back(flat_bvh_sphere{ { s.center[0], s.center[1], s.center[2] }, s.radius });
     }
 
     // triangles for the builder: corners fetched through the 24-bit vertex indices (src/scene.cpp:132-136)
@@ -63,6 +77,14 @@ scene::scene(const camera& cam, uint32_t width, uint32_t height, const scene_sou
 
     std::vector<packed_bvh_node> packed_nodes;
     std::vector<int32_t> ranks;
+    if (triangles.empty()) {
+        // a scene of spheres only: the threaded tree is one node that holds nothing (the kernel that walks it renders the sky)
+        packed_bvh_node none{};
+        none.next_id = -1;
+        none.primitive_id = -1;
+        packed_nodes.push_back(none);
+        bvh_mode = "no triangles";
+    } else
     try {
         bvh builder(triangles, packed_nodes);
         ranks = bvh::visit_ranks(packed_nodes, triangles.size());
@@ -78,8 +100,8 @@ scene::scene(const camera& cam, uint32_t width, uint32_t height, const scene_sou
     scene_buffer->write(&meta, sizeof(meta), sizeof(meta));
 
     auto upload = [](const void* data, size_t bytes) {
-        Buffer* b = hiprenderer::create_buffer(bytes);
-        b->write(data, 0, bytes);
+        Buffer* b = hiprenderer::create_buffer(bytes ? bytes : 48);   // (an array a scene of spheres leaves empty: 48 zero bytes, i.e. one record of whatever it holds)
+        if (bytes) b->write(data, 0, bytes);
         return b;
     };
     indices_buffer = upload(src.indices.data(), src.indices.size() * sizeof(uint32_t));
@@ -114,9 +136,15 @@ scene::scene(const camera& cam, uint32_t width, uint32_t height, const scene_sou
         hiprenderer::check(ptr_bvh_bind_flat(hiprenderer::api, bvh_buffer->device_buffer, flat_bvh_buffer->device_buffer), "ptr_bvh_bind_flat");
         bvh_mode += " + gpu radix tree";
     } else if (flatten_bvh) {
-        const std::vector<uint8_t> flat = bvh::flatten(triangles, ranks);
+        const std::vector<uint8_t> flat = bvh::flatten(triangles, ranks, 0, sphere_geometry);
         flat_bvh_buffer = upload(flat.data(), flat.size());
         hiprenderer::check(ptr_bvh_bind_flat(hiprenderer::api, bvh_buffer->device_buffer, flat_bvh_buffer->device_buffer), "ptr_bvh_bind_flat");
+        if (!sphere_records.empty()) {
+            spheres_buffer = upload(sphere_records.data(), sphere_records.size() * sizeof(gpu_sphere));
+            sphere_count = sphere_records.size();
+            hiprenderer::check(ptr_bvh_bind_spheres(hiprenderer::api, flat_bvh_buffer->device_buffer, spheres_buffer->device_buffer, (uint32_t)sphere_count), "ptr_bvh_bind_spheres");
+            bvh_mode += " + spheres";
+        }
     }
 }
 
@@ -159,7 +187,7 @@ void scene::place_copies_on_grid(uint32_t nx, uint32_t nz) {
 void scene::upload_metadata() const { scene_buffer->write(&meta, 0, sizeof(meta)); }
 
 scene::~scene() {
-    for (Buffer* b : { scene_buffer, indices_buffer, positions_buffer, normals_buffer, uvs_buffer, bvh_buffer, materials_buffer, flat_bvh_buffer, instances_buffer }) delete b;
+    for (Buffer* b : { scene_buffer, indices_buffer, positions_buffer, normals_buffer, uvs_buffer, bvh_buffer, materials_buffer, flat_bvh_buffer, instances_buffer, spheres_buffer }) delete b;
     for (Texture* t : textures) delete t;
     delete sampler;
 }

@@ -64,6 +64,8 @@ public:
     Buffer* materials_buffer = nullptr;
     Buffer* flat_bvh_buffer = nullptr;  // the flattened layout bound to bvh_buffer (wavefront path), may be null
     Buffer* instances_buffer = nullptr; // the top level over placed copies bound to flat_bvh_buffer, may be null
+    Buffer* spheres_buffer = nullptr;   // the shader's `sphere` records (compute.comp:31-36) named by the layout's sphere leaves, may be null
+    size_t sphere_count = 0;
     size_t copy_count = 1;
 
     size_t triangle_count = 0;

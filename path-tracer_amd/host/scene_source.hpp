@@ -28,7 +28,18 @@ struct scene_source {
     struct placement { uint32_t object; float object_to_world[12]; };
     std::vector<placement> placements;
 
+    // Spheres beside (or instead of) the triangles: the primitive of the reference's first scene (include/sphere.hpp:7-19), rendered
+    // through sphere leaves of the flattened layout.  Materials are given inline, as the shader's `sphere` struct holds them.
+    struct source_sphere { float center[3]; float radius; source_material material; };
+    std::vector<source_sphere> spheres;
+
     static scene_source load(const std::string& path);  // .ptrscene file, see scene_source.cpp
+    // One sphere per line: x y z radius r g b metalness roughness ('#' starts a comment).
+    static std::vector<source_sphere> load_spheres(const std::string& path);
+    // The scene the reference's README picture shows, after its commented-out scene::random_scene (src/scene.cpp:11-58): a ground
+    // sphere of radius 1000, a 22 x 22 field of small spheres with random diffuse / metal / mirror materials, three large ones.
+    // Deterministic in `seed` (the reference drew from rand()).
+    static std::vector<source_sphere> random_spheres(uint32_t seed);
 };
 
 #endif  // PTR_SCENE_SOURCE_HPP_

@@ -22,6 +22,8 @@ def lib():
         L.ptrh_bvh_flatten_spheres.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_uint32, C.POINTER(C.c_void_p),
                                                C.POINTER(C.c_uint64)]
         L.ptrh_bvh_flatten_spheres.restype = C.c_int32
+        L.ptrh_random_spheres.argtypes = [C.c_uint32, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]
+        L.ptrh_random_spheres.restype = C.c_int32
         L.ptrh_bvh_flatten_instances.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_int64, C.c_uint32, C.POINTER(C.c_void_p),
                                                  C.POINTER(C.c_uint64)]
         L.ptrh_bvh_flatten_instances.restype = C.c_int32
@@ -98,6 +100,18 @@ def bvh_flatten(triangles, ranks=None, threads=0, spheres=None):
     finally:
         lib().ptrh_free(ptr)
     return blob
+
+
+def random_spheres(seed):
+    """The reference's old scene of spheres (its commented-out scene::random_scene, src/scene.cpp:11-58), deterministic in `seed`:
+    an (n, 9) float32 array of x y z radius r g b metalness roughness."""
+    count = C.c_uint32()
+    if lib().ptrh_random_spheres(seed, None, 0, C.byref(count)) != 0:
+        raise HostError(lib().ptrh_last_error().decode())
+    out = np.zeros((count.value, 9), np.float32)
+    if lib().ptrh_random_spheres(seed, out.ctypes.data, count.value, C.byref(count)) != 0:
+        raise HostError(lib().ptrh_last_error().decode())
+    return out
 
 
 def bvh_flatten_instances(object_blob, object_to_world, threads=0):

@@ -32,6 +32,31 @@ def add_spheres(bundle, spheres):
     return dict(bundle, flat=flat, sphere_records=records)
 
 
+def sphere_tuples(rows9):
+    """(n, 9) rows of x y z radius r g b metalness roughness (host.random_spheres, a --spheres file) as add_spheres() takes them."""
+    out = []
+    for x, y, z, radius, r, g, b, metalness, roughness in np.asarray(rows9, np.float32):
+        m = np.zeros((), dtype=scenes.MATERIAL_DTYPE)
+        m["base_color"] = [r, g, b, 1.0]
+        m["metalness"] = metalness
+        m["roughness"] = roughness
+        out.append(((x, y, z), radius, m))
+    return out
+
+
+def spheres_only_bundle(rows9, width, height, camera, **meta_kw):
+    """A scene without a single triangle: every array the kernels are handed holds 48 zero bytes (one unused record), the threaded
+    tree is one node that holds nothing, the flattened layout has sphere leaves only."""
+    nodes = np.zeros((1, 8), np.uint32)
+    nodes[0, 3] = nodes[0, 7] = 0xFFFFFFFF
+    cam = host.camera(camera["pos"], camera["target"], camera["v_fov"], width / height, camera["aperture"], camera["focus"])
+    base = dict(kind="spheres", positions=np.zeros(12, np.float32), normals=np.zeros(12, np.float32), uvs=np.zeros(12, np.float32),
+                indices=np.zeros(12, np.uint32), materials=np.zeros(1, dtype=scenes.MATERIAL_DTYPE), textures=[None],
+                triangles=np.zeros((0, 9), np.float32), ranks=None, camera=camera, nodes=nodes,
+                meta=scenes.pack_metadata(cam, width, height, **meta_kw), width=width, height=height)
+    return add_spheres(base, sphere_tuples(rows9))
+
+
 def oracle_frames(bundle, spp, use_flat=False, materials=None, textures=None, aov=False, threads=None, first_sample=1, spheres=None):
     """Renders sample_index = first_sample .. first_sample+spp-1 with the CPU oracle, ping-ponging the two images
     like src/main.cpp:406-416.  Returns (image, counters of the last frame, (aov_prim, aov_t) of the last frame)."""

@@ -326,3 +326,62 @@ def test_headless_driver_renders_shared_meshes_as_placements(tmp_path):
     assert (hit >= 0).mean() > 0.08 and len(np.unique(hit[hit >= 0] // b["triangles"].shape[0])) >= 10, "several placements are in view"
     img = read_ptrf(out_file)
     assert np.array_equal(img, ref), f"{int((np.abs(img - ref).max(axis=2) > 0).sum())} pixels differ\n{r.stderr}"
+
+
+def write_spheres(path, rows9):
+    with open(path, "w") as f:
+        f.write("# x y z radius r g b metalness roughness\n")
+        for row in np.asarray(rows9, np.float32):
+            f.write(" ".join(repr(float(v)) for v in row) + "\n")
+
+
+def test_headless_driver_renders_spheres_beside_a_scene(tmp_path):
+    """--spheres FILE beside --scene: scene_source::load_spheres -> scene (bvh::flatten with spheres, ptr_bvh_bind_spheres) -> kernels;
+    the image equals the oracle's on the same triangles and spheres."""
+    from common import add_spheres, sphere_tuples
+    W, H, SPP = 72, 40, 3
+    b = make_bundle("atrium", 3000, W, H, max_bounce=5)
+    c = b["camera"]
+    eye, at = np.float32(c["pos"]), np.float32(c["target"])
+    along = (at - eye) / np.linalg.norm(at - eye)
+    rows = np.array([[*(eye + along * 3.0), 0.8, 0.9, 0.9, 0.9, 1.0, 0.0],               # a mirror ball in front of the camera
+                     [*(eye + along * 2.0 + np.float32([0.6, -0.4, 0.3])), 0.3, 0.8, 0.2, 0.2, 0.0, 1.0],
+                     [*(eye + along * 4.0 + np.float32([-1.0, 0.5, -0.5])), 0.5, 0.3, 0.5, 0.9, 1.0, 0.45]], np.float32)
+    scene_file, spheres_file, out_file = str(tmp_path / "scene.ptrscene"), str(tmp_path / "spheres.txt"), str(tmp_path / "out.pfm")
+    scenes.save_ptrscene(b, scene_file)
+    write_spheres(spheres_file, rows)
+    cmd = [HEADLESS, "--scene", scene_file, "--spheres", spheres_file, "--width", str(W), "--height", str(H), "--spp", str(SPP), "--max-bounce", "5",
+           "--out", out_file, "--pos", *map(str, c["pos"]), "--target", *map(str, c["target"]),
+           "--fov", str(c["v_fov"]), "--aperture", str(c["aperture"]), "--focus", str(c["focus"])]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    with_spheres = add_spheres(b, sphere_tuples(rows))
+    ref, _, aov = oracle_frames(with_spheres, SPP, use_flat=True, aov=True)
+    assert ((aov[0][..., 0] >= 0) & ((aov[0][..., 0] & 0x40000000) != 0)).any(), "the spheres are in view"
+    img = read_ptrf(out_file)
+    assert np.array_equal(img, ref), f"{int((np.abs(img - ref).max(axis=2) > 0).sum())} pixels differ\n{r.stderr}"
+    # placed copies of a scene with sphere leaves are refused, with the library's message
+    r = subprocess.run(cmd + ["--copies", "2", "2"], capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "sphere leaves cannot be instanced" in r.stderr, r.stderr
+
+
+def test_headless_driver_renders_the_old_scene_of_spheres(tmp_path):
+    """--random-spheres SEED, no triangle at all: the scene of the reference's commented-out scene::random_scene (src/scene.cpp:11-58),
+    486 spheres, through the C++ classes; equal to the oracle on the same spheres (which Python gets from the same generator)."""
+    from common import spheres_only_bundle
+    from path_tracer_amd import host
+    W, H, SPP = 96, 54, 4
+    rows = host.random_spheres(7)
+    assert rows.shape[0] > 400 and rows[0, 3] == 1000.0
+    camera = dict(pos=[13.0, 2.0, 3.0], target=[0.0, 0.0, 0.0], v_fov=20.0, aperture=0.1, focus=10.0)      # the book's view of it
+    b = spheres_only_bundle(rows, W, H, camera, max_bounce=6, enable_dof=1)
+    out_file = str(tmp_path / "out.pfm")
+    cmd = [HEADLESS, "--random-spheres", "7", "--width", str(W), "--height", str(H), "--spp", str(SPP), "--max-bounce", "6", "--dof", "1",
+           "--out", out_file, "--pos", "13", "2", "3", "--target", "0", "0", "0", "--fov", "20", "--aperture", "0.1", "--focus", "10"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    ref, _, aov = oracle_frames(b, SPP, use_flat=True, aov=True)
+    hit = aov[0][..., 0] >= 0
+    assert hit.mean() > 0.5 and ((aov[0][..., 0][hit] & 0x40000000) != 0).all()
+    img = read_ptrf(out_file)
+    assert np.array_equal(img, ref), f"{int((np.abs(img - ref).max(axis=2) > 0).sum())} pixels differ\n{r.stderr}"
