@@ -22,7 +22,8 @@ def main():
     ap.add_argument("--seed", type=int, default=1)
     args = ap.parse_args()
     import pyoracle
-    from common import make_bundle, oracle_frames
+    from common import add_spheres, make_bundle, oracle_frames
+    from path_tracer_amd import scenes
     from test_two_level import assorted_transforms, two_level_bundle
     from path_tracer_amd import hip
     pyoracle.build()
@@ -42,7 +43,22 @@ def main():
         if rng.random() < 0.25:
             meta_kw["downscale_factor"] = int(rng.integers(2, 4))
         b = make_bundle(kind, target, W, H, seed=int(rng.integers(1, 1 << 30)), **meta_kw)
-        tree = str(rng.choice(["host", "host", "gpu", "copies"]))
+        tree = str(rng.choice(["host", "host", "gpu", "copies", "spheres"]))
+        if tree == "spheres":     # sphere leaves among the triangles: anywhere in the scene's box, any material the scene could have
+            lo, hi = b["triangles"].reshape(-1, 3).min(axis=0), b["triangles"].reshape(-1, 3).max(axis=0)
+            extent = float((hi - lo).max())
+            eye = np.float32(b["camera"]["pos"])
+            spheres = []
+            for _ in range(int(rng.integers(1, 60))):
+                m = np.zeros((), dtype=scenes.MATERIAL_DTYPE)
+                m["base_color"] = list(rng.random(3)) + [1.0]
+                m["metalness"], m["roughness"] = [(0.0, 1.0), (1.0, 0.0), (1.0, float(rng.uniform(0.1, 0.9))), (float(rng.random()), float(rng.random()))][int(rng.integers(0, 4))]
+                if rng.random() < 0.3 and len(b["textures"]) > 1:
+                    m["albedo_tex"] = int(rng.integers(1, len(b["textures"])))
+                near = rng.random() < 0.4   # some of them around the camera, so that they are seen at any scene size
+                centre = (eye + rng.normal(size=3) * 0.08 * extent) if near else rng.uniform(lo, hi)
+                spheres.append((tuple(np.float32(centre)), float(rng.uniform(0.002, 0.06) * extent), m))
+            b = add_spheres(b, spheres)
         if tree == "copies":      # the scene placed several times through a top-level tree (rotated, scaled, one mirrored)
             b, _ = two_level_bundle(b, assorted_transforms(b, int(rng.integers(1, 7)), seed=int(rng.integers(1, 1000))), W, H, **meta_kw)
         spp = int(rng.integers(1, 8))
@@ -79,7 +95,8 @@ def main():
         finally:
             ctx.set_option("dispatch.coalesce", 1)
             ctx.set_partition(0, 1, 8)
-        ref, counters, _ = oracle_frames(b, spp, use_flat=not mega, materials=gs.materials_host, textures=gs.texture_table)
+        ref, counters, _ = oracle_frames(b, spp, use_flat=not mega, materials=gs.materials_host, textures=gs.texture_table,
+                                         spheres=gs.spheres_host if tree == "spheres" else None)
         d = meta_kw.get("downscale_factor", 1)
         # a rank owns rows of the DISPATCH domain (frame rows / downscale); its image rows follow from the block size
         owned = np.zeros(H, bool)
