@@ -391,7 +391,7 @@ int dispatch_compute(ptr_ctx* c, const uint8_t constants[64], uint32_t gx, uint3
                 PTR_HIP_CHECK(c, hipMemsetAsync(w.counters + s, 0, 4, ts));
                 PTR_HIP_CHECK(c, hipMemsetAsync(w.counters + ptr::kMaxBounceSlots + s, 0, 4, ts));
             }
-            PTR_HIP_CHECK(c, ptr::launch_wf_extend(ts, fv, w, b, sv.stats, c->opt_extend_refill, c->opt_extend_leaf_weight, c->opt_extend_leaf_all, c->opt_extend_inner_reps));
+            PTR_HIP_CHECK(c, ptr::launch_wf_extend(ts, fv, w, b, sv.stats, c->opt_extend_refill, c->opt_extend_leaf_weight, c->opt_extend_leaf_all, c->opt_extend_inner_reps, b + 1 == meta.max_bounce && !sv.capture));
             PTR_HIP_CHECK(c, ptr::launch_wf_shade(ts, sv, w, b, meta.max_bounce, meta.min_bounce, domain_w, domain_h));
         }
         PTR_HIP_CHECK(c, ptr::launch_wf_accumulate(ts, sv, w, domain_w, domain_h));
@@ -450,7 +450,7 @@ int dispatch_compute(ptr_ctx* c, const uint8_t constants[64], uint32_t gx, uint3
             PTR_HIP_CHECK(c, hipMemsetAsync(w.counters + s, 0, 4, ts));
             PTR_HIP_CHECK(c, hipMemsetAsync(w.counters + ptr::kMaxBounceSlots + s, 0, 4, ts));
         }
-        { ScopedProfile prof(c, "wavefront.extend", ts); PTR_HIP_CHECK(c, ptr::launch_wf_extend(ts, fv, w, b, sv.stats, c->opt_extend_refill, c->opt_extend_leaf_weight, c->opt_extend_leaf_all, c->opt_extend_inner_reps)); }
+        { ScopedProfile prof(c, "wavefront.extend", ts); PTR_HIP_CHECK(c, ptr::launch_wf_extend(ts, fv, w, b, sv.stats, c->opt_extend_refill, c->opt_extend_leaf_weight, c->opt_extend_leaf_all, c->opt_extend_inner_reps, b + 1 == meta.max_bounce && !sv.capture)); }
         { ScopedProfile prof(c, "wavefront.shade", ts); PTR_HIP_CHECK(c, ptr::launch_wf_shade(ts, sv, w, b, meta.max_bounce, meta.min_bounce, domain_w, domain_h)); }
     }
     if (overlap) {

@@ -77,8 +77,11 @@ hipError_t launch_stripes_copy(hipStream_t s, float4* image, uint32_t width, uin
 
 // Wavefront stages.  domain_w/h = pixels of the dispatch that exist (min(groups*8, width/height)).
 hipError_t launch_wf_generate(hipStream_t s, const SceneView& sv, const WavefrontScratch& w, uint32_t domain_w, uint32_t domain_h);
+// any_hit: the walk of a ray ends at the first triangle (or sphere) it hits; the published hit then says THAT the ray hits
+// something, not what or where.  For the last bounce of a path, where nothing else matters (compute.comp:130-136, 241-244: a path
+// that is still alive when the loop runs out contributes nothing, whatever it hit).
 hipError_t launch_wf_extend(hipStream_t s, const FlatView& fv, const WavefrontScratch& w, uint32_t bounce, unsigned long long* stats,
-                            int refill, int leaf_weight, int leaf_all, int inner_reps);
+                            int refill, int leaf_weight, int leaf_all, int inner_reps, bool any_hit = false);
 hipError_t launch_wf_shade(hipStream_t s, const SceneView& sv, const WavefrontScratch& w, uint32_t bounce, uint32_t max_bounce,
                            uint32_t min_bounce, uint32_t domain_w, uint32_t domain_h);
 // Fills the per-triangle shading records (kShadeRecordVec4 float4 each) from the index / positions / normals / uvs arrays

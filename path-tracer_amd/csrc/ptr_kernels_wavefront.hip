@@ -176,7 +176,9 @@ constexpr int32_t kTraversalDone = INT32_MIN;  // never a leaf reference: triang
 //     the kind: the world-space ray and its reciprocals wait in nine words of LDS per lane and come back where the marker
 //     is popped (re-reading the queue there, and taking a leaf turn for it, made the placed copies 37 % slower than the
 //     same copies written out).
-template <bool STATS, int REFILL, int LEAF_WEIGHT, bool LEAF_ALL, int INNER_REPS, bool TWO_LEVEL>
+//   * ANY_HIT: the first hit a lane finds ends its ray (the stack is dropped); used for the last bounce of a path, whose shade
+//     step only asks whether the ray escaped.
+template <bool STATS, int REFILL, int LEAF_WEIGHT, bool LEAF_ALL, int INNER_REPS, bool TWO_LEVEL, bool ANY_HIT = false>
 __global__ __launch_bounds__(kExtendThreads, TWO_LEVEL ? 6 : 4) void ptr_wf_extend(FlatView fv, WavefrontScratch w, uint32_t gen, uint32_t slot_b,
                                                                 unsigned long long* stats) {
     constexpr uint32_t kWaveWords = kStackLds * 64u + (TWO_LEVEL ? 9u * 64u : 0u);   // a wave's stacks, then its lanes' world-space rays
@@ -366,6 +368,7 @@ __global__ __launch_bounds__(kExtendThreads, TWO_LEVEL ? 6 : 4) void ptr_wf_exte
                 if (!reject && !(best_prim >= 0 && t == best_t && earlier)) {
                     best_t = t; best_u = u; best_v = v; best_rank = rank; best_prim = __float_as_int(b.w);
                     if (TWO_LEVEL) best_inst = cur_inst;
+                    if (ANY_HIT) { ref = 0xffffffffu; sp = 0u; break; }   // nothing pending matters any more
                 }
                 if (remaining == 0u) { ref = 0xffffffffu; break; }
                 ref = ((first + 1u) << 2) | (remaining - 1u);
@@ -575,6 +578,7 @@ __global__ __launch_bounds__(kExtendThreads, TWO_LEVEL ? 6 : 4) void ptr_wf_exte
                 const bool earlier = TWO_LEVEL ? (ccopy < bcopy || (ccopy == bcopy && crank < brank)) : crank < brank;
                 if (cprim >= 0 && !(bprim >= 0 && ct == bt && earlier)) { bt = ct; bu = cu; bv = cv; brank = crank; bprim = cprim; bcopy = ccopy; }
             }
+            if (ANY_HIT && bprim >= 0) break;   // wave-uniform
             // append the entered children: farthest first within a lane, so that a depth-first turn pops the nearest
             const unsigned long long b0 = __ballot((n_push & 1u) != 0u), b1 = __ballot((n_push & 2u) != 0u), b2 = __ballot((n_push & 4u) != 0u);
             const unsigned long long below = (1ull << lane) - 1ull;
@@ -660,8 +664,15 @@ __global__ __launch_bounds__(kShadeThreads) void ptr_wf_shade(SceneView sv, Wave
             if (bounce == 0u) { c->prim0 = named; c->t0 = h.prim >= 0 ? h.t : 0.0f; }
             else { c->prim1 = named; c->t1 = h.prim >= 0 ? h.t : 0.0f; }
         }
-        go_on = shade_bounce(sv, bounce, min_bounce, h, r, throughput, seed, result);
-        if (go_on && bounce + 1u >= max_bounce) { go_on = false; result = mk3(0.0f, 0.0f, 0.0f); }  // loop exhausted: radiance
+        if (!STATS && bounce + 1u >= max_bounce) {
+            // the last turn of the bounce loop: a ray that escapes returns the path's throughput (compute.comp:130-136), and whatever
+            // else happens to the path -- absorbed, ended by the roulette, or still alive when the loop runs out (compute.comp:241-244)
+            // -- it returns black: only hit-or-miss is looked at (the traversal of this bounce stops at the first hit it finds)
+            result = h.prim < 0 ? throughput * 1.0f : mk3(0.0f, 0.0f, 0.0f);
+        } else {
+            go_on = shade_bounce(sv, bounce, min_bounce, h, r, throughput, seed, result);
+            if (go_on && bounce + 1u >= max_bounce) { go_on = false; result = mk3(0.0f, 0.0f, 0.0f); }  // loop exhausted: radiance
+        }
         if (!go_on) stream_store(&w.samples[pixel], make_float4(result.x, result.y, result.z, 1.0f));
     }
 
@@ -731,24 +742,29 @@ hipError_t launch_wf_generate(hipStream_t s, const SceneView& sv, const Wavefron
     return hipGetLastError();
 }
 
-template <bool STATS, int LEAF_WEIGHT, bool LEAF_ALL, int INNER_REPS, bool TWO_LEVEL = false>
+template <bool STATS, int LEAF_WEIGHT, bool LEAF_ALL, int INNER_REPS, bool TWO_LEVEL = false, bool ANY_HIT = false>
 static void launch_extend_variant(hipStream_t s, const FlatView& fv, const WavefrontScratch& w, uint32_t bounce, unsigned long long* stats,
                                   int refill) {
     const uint32_t slot_b = bounce % kMaxBounceSlots;
     const dim3 grid(w.extend_blocks), block(kExtendThreads);
     switch (refill) {
-    case 8: hipLaunchKernelGGL((ptr_wf_extend<STATS, 8, LEAF_WEIGHT, LEAF_ALL, INNER_REPS, TWO_LEVEL>), grid, block, 0, s, fv, w, bounce & 1u, slot_b, stats); break;
-    case 16: hipLaunchKernelGGL((ptr_wf_extend<STATS, 16, LEAF_WEIGHT, LEAF_ALL, INNER_REPS, TWO_LEVEL>), grid, block, 0, s, fv, w, bounce & 1u, slot_b, stats); break;
-    case 32: hipLaunchKernelGGL((ptr_wf_extend<STATS, 32, LEAF_WEIGHT, LEAF_ALL, INNER_REPS, TWO_LEVEL>), grid, block, 0, s, fv, w, bounce & 1u, slot_b, stats); break;
-    default: hipLaunchKernelGGL((ptr_wf_extend<STATS, 64, LEAF_WEIGHT, LEAF_ALL, INNER_REPS, TWO_LEVEL>), grid, block, 0, s, fv, w, bounce & 1u, slot_b, stats); break;
+    case 8: hipLaunchKernelGGL((ptr_wf_extend<STATS, 8, LEAF_WEIGHT, LEAF_ALL, INNER_REPS, TWO_LEVEL, ANY_HIT>), grid, block, 0, s, fv, w, bounce & 1u, slot_b, stats); break;
+    case 16: hipLaunchKernelGGL((ptr_wf_extend<STATS, 16, LEAF_WEIGHT, LEAF_ALL, INNER_REPS, TWO_LEVEL, ANY_HIT>), grid, block, 0, s, fv, w, bounce & 1u, slot_b, stats); break;
+    case 32: hipLaunchKernelGGL((ptr_wf_extend<STATS, 32, LEAF_WEIGHT, LEAF_ALL, INNER_REPS, TWO_LEVEL, ANY_HIT>), grid, block, 0, s, fv, w, bounce & 1u, slot_b, stats); break;
+    default: hipLaunchKernelGGL((ptr_wf_extend<STATS, 64, LEAF_WEIGHT, LEAF_ALL, INNER_REPS, TWO_LEVEL, ANY_HIT>), grid, block, 0, s, fv, w, bounce & 1u, slot_b, stats); break;
     }
 }
 
 hipError_t launch_wf_extend(hipStream_t s, const FlatView& fv, const WavefrontScratch& w, uint32_t bounce, unsigned long long* stats,
-                            int refill, int leaf_weight, int leaf_all, int inner_reps) {
+                            int refill, int leaf_weight, int leaf_all, int inner_reps, bool any_hit) {
+    // (the counting variants and the tuning configurations always look for the closest hit: the counts they report are the
+    // oracle's, and a closest hit is an answer to "any hit?" as well)
     if (fv.top.nodes) {  // placed copies: one configuration, the default one
         if (stats) launch_extend_variant<true, 2, true, 3, true>(s, fv, w, bounce, stats, refill);
+        else if (any_hit) launch_extend_variant<false, 2, true, 3, true, true>(s, fv, w, bounce, stats, refill);
         else launch_extend_variant<false, 2, true, 3, true>(s, fv, w, bounce, stats, refill);
+    } else if (!stats && any_hit && leaf_all && inner_reps >= 3) {
+        launch_extend_variant<false, 2, true, 3, false, true>(s, fv, w, bounce, stats, refill);
     } else if (stats) {  // the counting variant follows inner_reps so that its step counts describe the timed configuration
         if (inner_reps >= 3) launch_extend_variant<true, 2, true, 3>(s, fv, w, bounce, stats, refill);
         else launch_extend_variant<true, 2, true, 1>(s, fv, w, bounce, stats, refill);

@@ -1026,3 +1026,28 @@ def test_present_style_readback_converts_on_the_device(ctx):
         small.read_unorm8()
     for x in (t, small):
         x.destroy()
+
+
+@pytest.mark.parametrize("turns", [0, 1000000])
+@pytest.mark.parametrize("bounces", [1, 2, 3, 5])
+def test_last_bounce_stops_at_the_first_hit_and_the_image_does_not_change(ctx, bounces, turns):
+    """The traversal of a path's last bounce ends at the first hit it finds and its shade step only asks whether the ray escaped
+    (compute.comp:130-136, 241-244: a path that hit something on its last bounce contributes nothing, whatever it hit) -- unless
+    the per-pixel capture is on, which wants the closest hit.  Images with and without the capture equal the oracle's."""
+    from test_spheres import sphere_set
+    from common import add_spheres
+    for kind, target, w, h in (("tiny", 0, 50, 37), ("atrium", 5000, 96, 54)):
+        b = make_bundle(kind, target, w, h, max_bounce=bounces, min_bounce=0)
+        if kind == "tiny":
+            b = add_spheres(b, sphere_set())
+        ctx.set_option("extend.alone_turns", turns)
+        try:
+            img, gs, _, _ = gpu_frames(ctx, b, 3, "compute.wavefront")
+            img_cap, _, cap, _ = gpu_frames(ctx, b, 3, "compute.wavefront", gpu_scene=gs, capture=True)
+        finally:
+            ctx.set_option("extend.alone_turns", 0)
+        ref, _, aov = oracle_frames(b, 3, use_flat=True, aov=True, materials=gs.materials_host, textures=gs.texture_table,
+                                    spheres=getattr(gs, "spheres_host", None) if kind == "tiny" else None)
+        assert_same(img, ref, f"{kind}, {bounces} bounces, first hit on the last one")
+        assert_same(img_cap, ref, f"{kind}, {bounces} bounces, with the capture (closest hits throughout)")
+        assert_same(cap[0], aov[0], "captured primitive ids")

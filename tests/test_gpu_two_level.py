@@ -142,3 +142,19 @@ def test_wide_frontier_inside_placed_copies(ctx):
     same(cap[0], aov[0], "copy * triangles + primitive of the first two hits")
     same(cap[1], aov[1], "hit distances")
     same(img, ref, "image")
+
+
+@pytest.mark.parametrize("turns", [0, 1000000])
+@pytest.mark.parametrize("bounces", [1, 2, 4])
+def test_two_level_last_bounce_stops_at_the_first_hit(ctx, bounces, turns):
+    """Without the capture the traversal of the last bounce ends at the first hit, also inside a copy and in the cooperative
+    finish of a wave's last ray: the image stays the oracle's."""
+    base = make_bundle("atrium", 4000, 32, 24)
+    two, _ = two_level_bundle(base, assorted_transforms(base, 6), 96, 60, max_bounce=bounces, min_bounce=0)
+    ctx.set_option("extend.alone_turns", turns)
+    try:
+        img, gs, _, _ = gpu_frames(ctx, two, 3, "compute.wavefront")
+    finally:
+        ctx.set_option("extend.alone_turns", 0)
+    ref, _, _ = oracle_for(two, gs, 3, use_flat=True)
+    same(img, ref, f"{bounces} bounces")
