@@ -348,8 +348,9 @@ def result_line(args, sc, W, H, world, tiles, elapsed, t1_elapsed, rays_total, s
                     "bytes_per_unit": {"node": node_bytes, "triangle": tri_bytes}}
     roofline.update({"launches": k["launches"], "avg_launch_ms": avg_ms, "solo_avg_launch_ms": solo_ms,
                      "nodes_per_ray": stats["nodes"] / max(1, stats["rays"]), "triangles_per_ray": stats["triangles"] / max(1, stats["rays"]),
-                     "counts_note": "nodes and triangles are counted by the counting variant of the same kernel, which walks every ray with one lane; "
-                                    "the timed variant finishes each wave's last ray with all 64 lanes and can touch a few more nodes on those rays",
+                     "counts_note": "nodes and triangles are counted by the counting variant of the same kernel, which walks every ray with one lane to its closest hit; "
+                                    "the timed variant finishes each wave's last ray with all 64 lanes (a few more nodes on those rays) and ends the rays of a "
+                                    "path's last bounce at their first hit (fewer)",
                      "limiter": "instruction issue on the one-pipe class under divergence together with the rate of L1 accesses (vector_memory): the BVH is served by L2 / Infinity Cache "
                                 "and the memory side moves a third of the algorithmic bytes, also on the 100 M-triangle scene",
                      "lane_utilisation": lane_util, "counters": traffic_part})
