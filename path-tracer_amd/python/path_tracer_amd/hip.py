@@ -406,6 +406,7 @@ class GpuScene:
             self.instance_buffer = upload(arrays["flat_instances"])
             ctx.bind_instances(self.flat_buffer, self.instance_buffer)
         self.sphere_buffer = None
+        self.spheres_host = None
         if flat is not None and arrays.get("sphere_records") is not None:
             records = np.array(arrays["sphere_records"], dtype=scenes.SPHERE_DTYPE, copy=True)
             m = records["material"]   # the embedded materials name textures the same way the material buffer does

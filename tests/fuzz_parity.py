@@ -96,7 +96,7 @@ def main():
             ctx.set_option("dispatch.coalesce", 1)
             ctx.set_partition(0, 1, 8)
         ref, counters, _ = oracle_frames(b, spp, use_flat=not mega, materials=gs.materials_host, textures=gs.texture_table,
-                                         spheres=gs.spheres_host if tree == "spheres" else None)
+                                         spheres=gs.spheres_host)
         d = meta_kw.get("downscale_factor", 1)
         # a rank owns rows of the DISPATCH domain (frame rows / downscale); its image rows follow from the block size
         owned = np.zeros(H, bool)

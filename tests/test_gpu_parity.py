@@ -1047,7 +1047,7 @@ def test_last_bounce_stops_at_the_first_hit_and_the_image_does_not_change(ctx, b
         finally:
             ctx.set_option("extend.alone_turns", 0)
         ref, _, aov = oracle_frames(b, 3, use_flat=True, aov=True, materials=gs.materials_host, textures=gs.texture_table,
-                                    spheres=getattr(gs, "spheres_host", None) if kind == "tiny" else None)
+                                    spheres=gs.spheres_host)
         assert_same(img, ref, f"{kind}, {bounces} bounces, first hit on the last one")
         assert_same(img_cap, ref, f"{kind}, {bounces} bounces, with the capture (closest hits throughout)")
         assert_same(cap[0], aov[0], "captured primitive ids")
