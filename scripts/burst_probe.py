@@ -27,6 +27,8 @@ def main():
     ap.add_argument("--bvh", default="host", choices=["host", "gpu"])
     ap.add_argument("--in-flight", type=int, default=2)
     ap.add_argument("--reset", action="store_true", help="restart the sample index with every chunk")
+    ap.add_argument("--per-dispatch", type=int, default=1, help="samples per dispatch (1 = the reference's protocol)")
+    ap.add_argument("--summary", action="store_true", help="print the distribution of the chunks' times instead of every chunk (long soaks)")
     ap.add_argument("--per-sample", type=int, default=0, help="instead: print rays, nodes per ray and ms of each of the first N sample indices")
     args = ap.parse_args()
     import bench
@@ -37,7 +39,7 @@ def main():
     if args.bvh == "gpu":
         gpu.wire(ctx.create_compute_renderpass())
         ctx.bind_flat(gpu.bvh_buffer, ctx.build_flat(gpu.indices_buffer, gpu.positions_buffer, sc["triangles"].shape[0]))
-    loop = hip.FrameLoop(ctx, gpu, args.width, args.height, "compute")
+    loop = hip.FrameLoop(ctx, gpu, args.width, args.height, "compute", samples_per_dispatch=args.per_dispatch)
     ctx.set_option("frames.in_flight", args.in_flight)
     loop.frame(); ctx.sync()
     if args.per_sample:
@@ -61,11 +63,22 @@ def main():
         if args.pause:
             time.sleep(args.pause)
         t0 = time.perf_counter()
-        for _ in range(n):
-            loop.frame()
+        if args.per_dispatch > 1:
+            loop.frames(n)
+        else:
+            for _ in range(n):
+                loop.frame()
         ctx.sync()
         out.append((n, round((time.perf_counter() - t0) / n * 1e3, 3)))
-    print(" ".join(f"{n}:{ms}" for n, ms in out), flush=True)
+        if args.summary and len(out) % 500 == 0:
+            print(f"... {len(out)} chunks", flush=True)
+    if args.summary:
+        ms = sorted(m for _, m in out)
+        pick = lambda q: ms[min(len(ms) - 1, int(q * len(ms)))]
+        print(f"{sum(n for n, _ in out)} steps in {len(out)} chunks, {args.per_dispatch} sample(s) per dispatch: ms per step median {pick(0.5):.3f}, "
+              f"90th percentile {pick(0.9):.3f}, 99th {pick(0.99):.3f}, worst chunk {ms[-1]:.3f}, best {ms[0]:.3f}", flush=True)
+    else:
+        print(" ".join(f"{n}:{ms}" for n, ms in out), flush=True)
     ctx.close()
 
 
