@@ -89,8 +89,11 @@ std::vector<scene_source::source_sphere> scene_source::random_spheres(uint32_t s
         return s;
     };
     std::vector<source_sphere> out;
-    // `material m = {...}` leaves metalness and roughness at the struct's defaults, 1 and 1 (include/material.hpp:13-14)
-    out.push_back(make(0.f, -1000.f, 0.f, 1000.f, 0.5f, 0.5f, 0.5f, 1.f, 1.f));
+    // The commented code leaves metalness and roughness at the struct's defaults (1 and 1, include/material.hpp:13-14), and a surface
+    // of metalness 1 reflects nothing under today's shader (its specular F0 is taken from the diffuse reflectance, which is 0
+    // there).  The book's three material kinds are therefore mapped onto what the shader does render: diffuse = metalness 0,
+    // roughness 1; metal = metalness 0 .. 0.5 and roughness 0, as the commented code has it; glass = a smooth half-metal.
+    out.push_back(make(0.f, -1000.f, 0.f, 1000.f, 0.5f, 0.5f, 0.5f, 0.f, 1.f));
     const int n = 11;
     for (int a = -n; a < n; a++)
         for (int b = -n; b < n; b++) {
@@ -100,17 +103,16 @@ std::vector<scene_source::source_sphere> scene_source::random_spheres(uint32_t s
             if (std::sqrt(dx * dx + dy * dy + dz * dz) <= 0.9f) continue;
             if (choose < 0.8f) {          // diffuse
                 const float r = randd() * randd(), g = randd() * randd(), bl = randd() * randd();
-                out.push_back(make(cx, cy, cz, 0.2f, r, g, bl, 1.f, 1.f));
+                out.push_back(make(cx, cy, cz, 0.2f, r, g, bl, 0.f, 1.f));
             } else if (choose < 0.95f) {  // metal
                 const float r = 0.5f + 0.5f * randd(), g = 0.5f + 0.5f * randd(), bl = 0.5f + 0.5f * randd();
                 out.push_back(make(cx, cy, cz, 0.2f, r, g, bl, 0.5f * randd(), 0.f));
-            } else {                      // "glass" in the book; the commented code makes it a mirror (metalness 1, roughness 0) and leaves
-                                          // its colour unset -- white here, so that it reflects something
-                out.push_back(make(cx, cy, cz, 0.2f, 1.f, 1.f, 1.f, 1.f, 0.f));
+            } else {                      // glass
+                out.push_back(make(cx, cy, cz, 0.2f, 1.f, 1.f, 1.f, 0.5f, 0.f));
             }
         }
-    out.push_back(make(0.f, 1.f, 0.f, 1.f, 1.f, 1.f, 1.f, 1.f, 0.f));       // the book's glass ball (material1 = {} in the commented code): a white mirror here
-    out.push_back(make(-4.f, 1.f, 0.f, 1.f, 0.4f, 0.2f, 0.1f, 1.f, 1.f));
-    out.push_back(make(4.f, 1.f, 0.f, 1.f, 0.7f, 0.6f, 0.5f, 1.f, 0.f));
+    out.push_back(make(0.f, 1.f, 0.f, 1.f, 1.f, 1.f, 1.f, 0.5f, 0.f));      // the book's glass ball
+    out.push_back(make(-4.f, 1.f, 0.f, 1.f, 0.4f, 0.2f, 0.1f, 0.f, 1.f));   // its diffuse one
+    out.push_back(make(4.f, 1.f, 0.f, 1.f, 0.7f, 0.6f, 0.5f, 0.5f, 0.f));   // its metal one
     return out;
 }
