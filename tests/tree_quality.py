@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Nodes and triangles per ray of the flattened layout on the bench workload, counted by the CPU oracle on bands of rows
 spread over the frame: what a change to the builder is worth before any GPU time is spent on it (the traversal kernel is
-bound by VALU issue, so its time follows 113 x nodes + 67 x triangles per ray).  Kept beside the tests because it runs the
+bound by instruction issue, so its time follows 125 x nodes + 66 x triangles per ray).  Kept beside the tests because it runs the
 oracle; pytest does not collect it."""
 import argparse, os, sys, time
 import numpy as np
@@ -43,4 +43,4 @@ for s in range(1, a.samples + 1):
         for k in tot: tot[k] += r[k]
 n, t = tot["nodes"] / tot["rays"], tot["triangles"] / tot["rays"]
 print(f"triangles {sc['triangles'].shape[0]}  flat bytes {len(flat) if hasattr(flat, '__len__') else 0}  build {t2 - t1:.1f}s  rays {tot['rays']}  "
-      f"nodes/ray {n:.3f}  tris/ray {t:.3f}  valu/ray {113 * n + 67 * t:.0f}")
+      f"nodes/ray {n:.3f}  tris/ray {t:.3f}  valu/ray {125 * n + 66 * t:.0f}")
